@@ -1,0 +1,223 @@
+"""CPU ORACLE for the LFT forward hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.
+The product path (lft_amd/ + liblft_hip.so) never calls it and has no CPU fallback.
+
+What it is: a functional restatement, on stock PyTorch CPU operators, of the algorithm of the
+reference's model/LFT.py forward.  Every function cites the reference lines it follows.  It keeps
+the reference's operator sequence (dense additive window mask fed to scaled-dot-product attention,
+unfold + linear for the spatial token embedding, per-view bicubic) so that timing it on host cores
+is a fair stand-in for "the reference CPU path" (cpu_baseline kind = "port").
+
+Pinning: tests/test_oracle_golden.py checks this file against fixtures under tests/golden/ that
+tools/gen_golden.py produced by importing the real reference module in the build container
+(the reference has no tests or golden vectors of its own -- SURVEY.md section 8c).
+
+Third-party arithmetic: the reference's arithmetic lives in PyTorch (README pins 1.3.0; the
+container and the GPU box run 2.10.0+rocm7.0 on CPU).  Semantics relied on: bicubic A=-0.75 with
+align_corners=False and clamped taps, LayerNorm eps 1e-5, MultiheadAttention = packed in_proj
+(q,k from the query/key input, v from the value input), scale 1/sqrt(head_dim), softmax over keys,
+out_proj without bias.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+HEADS = 8          # reference LFT.py:19
+LAYERS = 4         # reference LFT.py:15
+WINDOW = 5         # reference LFT.py:123
+TEMPERATURE = 10000.0  # reference LFT.py:17
+
+
+# --------------------------------------------------------------------------------------------
+# small pieces
+# --------------------------------------------------------------------------------------------
+def mosaic_to_views(x: torch.Tensor, A: int) -> torch.Tensor:
+    """[B,c,A*h,A*w] -> [B,c,A*A,h,w]; view index v = a1*A + a2 (reference LFT.py:58)."""
+    B, c, H, W = x.shape
+    h, w = H // A, W // A
+    return x.reshape(B, c, A, h, A, w).permute(0, 1, 2, 4, 3, 5).reshape(B, c, A * A, h, w)
+
+
+def views_to_mosaic(x: torch.Tensor, A: int) -> torch.Tensor:
+    """[B,c,A*A,h,w] -> [B,c,A*h,A*w] (reference LFT.py:79)."""
+    B, c, V, h, w = x.shape
+    return x.reshape(B, c, A, A, h, w).permute(0, 1, 2, 4, 3, 5).reshape(B, c, A * h, A * w)
+
+
+def bicubic_skip(lr: torch.Tensor, A: int, s: int) -> torch.Tensor:
+    """Per-view bicubic x s of the LR mosaic, re-assembled as a mosaic (reference LFT.py:255-266)."""
+    B, _, H, W = lr.shape
+    v = mosaic_to_views(lr, A)                               # [B,1,V,h,w]
+    v = v.reshape(B * A * A, 1, H // A, W // A)
+    v = F.interpolate(v, scale_factor=s, mode="bicubic", align_corners=False)
+    v = v.reshape(B, 1, A * A, (H // A) * s, (W // A) * s)
+    return views_to_mosaic(v, A)
+
+
+def sinusoid_table(length: int, dim: int) -> torch.Tensor:
+    """[length, dim] rows concat(sin(p[:,0::2]), cos(p[:,1::2])), p[l,i] = l / T^(2*(i//2)/dim)
+    (reference LFT.py:94-104: sin block first, then cos block -- not interleaved)."""
+    i = torch.arange(dim, dtype=torch.float32)
+    g = TEMPERATURE ** (2 * torch.div(i, 2, rounding_mode="floor") / dim)
+    p = torch.arange(length, dtype=torch.float32).view(-1, 1) / g
+    return torch.cat([p[:, 0::2].sin(), p[:, 1::2].cos()], dim=1)
+
+
+def spatial_pe(h: int, w: int, dim: int) -> torch.Tensor:
+    """[dim,h,w] = (PE_h[y] + PE_w[x]) / 2 (reference LFT.py:69,107-115 with dim=[3,4])."""
+    return ((sinusoid_table(h, dim).view(h, 1, dim) + sinusoid_table(w, dim).view(1, w, dim)) / 2).permute(2, 0, 1)
+
+
+def angular_pe(V: int, dim: int) -> torch.Tensor:
+    """[V,dim] (reference LFT.py:70 with dim=[2]; divided by len(dim)=1)."""
+    return sinusoid_table(V, dim)
+
+
+def window_mask(h: int, w: int, k: int = WINDOW) -> torch.Tensor:
+    """Additive [h*w,h*w] mask: 0 inside the clamped k x k window of the query, -inf outside
+    (reference LFT.py:147-162).  The reference clamps the column range with ``h`` (not ``w``) at
+    :155; reproduced faithfully, which only matters for h != w."""
+    kl, kr = k // 2, k - k // 2
+    yy = torch.arange(h).view(h, 1, 1, 1)
+    xx = torch.arange(w).view(1, w, 1, 1)
+    ky = torch.arange(h).view(1, 1, h, 1)
+    kx = torch.arange(w).view(1, 1, 1, w)
+    rows = (ky >= (yy - kl).clamp(min=0)) & (ky < (yy + kr).clamp(max=h))
+    cols = (kx >= (xx - kl).clamp(min=0)) & (kx < (xx + kr).clamp(max=h))   # sic: h
+    inside = (rows & cols).reshape(h * w, h * w)
+    m = torch.full((h * w, h * w), float("-inf"))
+    m[inside] = 0.0
+    return m
+
+
+def mha(q_in: torch.Tensor, v_in: torch.Tensor, w_in: torch.Tensor, w_out: torch.Tensor,
+        mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """nn.MultiheadAttention(E, 8, bias=False) with query=key=q_in, value=v_in, [L,N,E] layout
+    (reference LFT.py:183-187, 230-233).  q,k projected from q_in, v from v_in; head c//(E/8)."""
+    L, N, E = q_in.shape
+    d = E // HEADS
+    wq, wk, wv = w_in[:E], w_in[E:2 * E], w_in[2 * E:]
+    q = (q_in @ wq.t()).reshape(L, N, HEADS, d).permute(1, 2, 0, 3)     # [N,H,L,d]
+    k = (q_in @ wk.t()).reshape(L, N, HEADS, d).permute(1, 2, 0, 3)
+    v = (v_in @ wv.t()).reshape(L, N, HEADS, d).permute(1, 2, 0, 3)
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)          # scale 1/sqrt(d)
+    o = o.permute(2, 0, 1, 3).reshape(L, N, E)
+    return o @ w_out.t()
+
+
+def ffn(t: torch.Tensor, ln_w, ln_b, w1, w2) -> torch.Tensor:
+    """LayerNorm -> Linear -> ReLU -> Linear, no biases, dropout 0 (reference LFT.py:135-142, 207-214)."""
+    n = F.layer_norm(t, (t.shape[-1],), ln_w, ln_b, 1e-5)
+    return F.relu(n @ w1.t()) @ w2.t()
+
+
+# --------------------------------------------------------------------------------------------
+# blocks; activations in the reference's [B,C,V,h,w] layout
+# --------------------------------------------------------------------------------------------
+def conv_views(x: torch.Tensor, wgt: torch.Tensor) -> torch.Tensor:
+    """Conv3d kernel (1,3,3) pad (0,1,1) no bias == per-view 3x3 conv (reference LFT.py:24,27-31)."""
+    return F.conv3d(x, wgt, padding=(0, 1, 1))
+
+
+def init_features(sd: Dict[str, torch.Tensor], lr_views: torch.Tensor) -> torch.Tensor:
+    """conv_init0 then 3 x (conv + LeakyReLU 0.2), plus residual (reference LFT.py:65-66)."""
+    f0 = conv_views(lr_views, sd["conv_init0.0.weight"])
+    f = f0
+    for i in (0, 2, 4):
+        f = F.leaky_relu(conv_views(f, sd[f"conv_init.{i}.weight"]), 0.2)
+    return f + f0
+
+
+def ang_block(sd, l: int, x: torch.Tensor) -> torch.Tensor:
+    """AngTrans.forward (reference LFT.py:225-238): tokens 'b c a h w -> a (b h w) c'."""
+    p = f"altblock.{l}.ang_trans."
+    B, C, V, h, w = x.shape
+    t = x.permute(2, 0, 3, 4, 1).reshape(V, B * h * w, C)
+    pe = angular_pe(V, C).view(V, 1, C)
+    n = F.layer_norm(t + pe, (C,), sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5)
+    t = mha(n, t, sd[p + "attention.in_proj_weight"], sd[p + "attention.out_proj.weight"], None) + t
+    t = ffn(t, sd[p + "feed_forward.0.weight"], sd[p + "feed_forward.0.bias"],
+            sd[p + "feed_forward.1.weight"], sd[p + "feed_forward.4.weight"]) + t
+    return t.reshape(V, B, h, w, C).permute(1, 4, 0, 2, 3)
+
+
+def spa_tokens(x: torch.Tensor, mlp_w: torch.Tensor) -> torch.Tensor:
+    """SpaTrans.SAI2Token (reference LFT.py:164-169): unfold 3x3 (zero pad per view, feature index
+    c*9+ky*3+kx) then Linear 576->128.  x [B,C,V,h,w] -> [h*w, B*V, 2C]."""
+    B, C, V, h, w = x.shape
+    img = x.permute(0, 2, 1, 3, 4).reshape(B * V, C, h, w)
+    u = F.unfold(img, kernel_size=3, padding=1).permute(2, 0, 1)
+    return u @ mlp_w.t()
+
+
+def spa_block(sd, l: int, x: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """SpaTrans.forward (reference LFT.py:176-191) followed by Token2SAI's 1x1x1 conv (:171-174)."""
+    p = f"altblock.{l}.spa_trans."
+    B, C, V, h, w = x.shape
+    if mask is None:
+        mask = window_mask(h, w)
+    t = spa_tokens(x, sd[p + "MLP.weight"])
+    pe = spa_tokens(spatial_pe(h, w, C).view(1, C, 1, h, w), sd[p + "MLP.weight"])
+    n = F.layer_norm(t + pe, (2 * C,), sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5)
+    t = mha(n, t, sd[p + "attention.in_proj_weight"], sd[p + "attention.out_proj.weight"], mask) + t
+    t = ffn(t, sd[p + "feed_forward.0.weight"], sd[p + "feed_forward.0.bias"],
+            sd[p + "feed_forward.1.weight"], sd[p + "feed_forward.4.weight"]) + t
+    t = t.reshape(h, w, B, V, 2 * C).permute(2, 4, 3, 0, 1)               # [B,2C,V,h,w]
+    return F.conv3d(t, sd[p + "linear.0.weight"])
+
+
+def upsample(sd, x_mosaic: torch.Tensor, s: int) -> torch.Tensor:
+    """1x1 conv -> PixelShuffle(s) -> LeakyReLU 0.2 -> 3x3 conv over the whole mosaic
+    (reference LFT.py:39-44, 80)."""
+    u = F.conv2d(x_mosaic, sd["upsampling.0.weight"])
+    u = F.leaky_relu(F.pixel_shuffle(u, s), 0.2)
+    return F.conv2d(u, sd["upsampling.3.weight"], padding=1)
+
+
+@torch.no_grad()
+def forward(sd: Dict[str, torch.Tensor], lr: torch.Tensor, A: int, s: int,
+            taps: Optional[dict] = None) -> torch.Tensor:
+    """get_model.forward (reference LFT.py:52-83).  lr [B,1,A*h,A*w] float32 -> [B,1,A*h*s,A*w*s].
+    ``taps`` (optional dict) receives intermediate activations in [B,C,V,h,w] layout."""
+    skip = bicubic_skip(lr, A, s)
+    x = init_features(sd, mosaic_to_views(lr, A))
+    h, w = x.shape[-2:]
+    mask = window_mask(h, w)
+    if taps is not None:
+        taps["skip"] = skip
+        taps["conv0"] = conv_views(mosaic_to_views(lr, A), sd["conv_init0.0.weight"])
+        taps["feat"] = x
+    y = x
+    for l in range(LAYERS):
+        y = ang_block(sd, l, y)                     # angular first (reference LFT.py:249-250)
+        if taps is not None:
+            taps[f"ang{l}"] = y
+        y = spa_block(sd, l, y, mask)
+        if taps is not None:
+            taps[f"spa{l}"] = y
+    y = y + x                                        # reference LFT.py:76
+    r = upsample(sd, views_to_mosaic(y, A), s)
+    if taps is not None:
+        taps["body"] = y
+        taps["res"] = r
+    return r + skip                                  # reference LFT.py:81
+
+
+def l1_loss(sr: torch.Tensor, hr: torch.Tensor) -> torch.Tensor:
+    """get_loss.forward: mean absolute error (reference LFT.py:269-277)."""
+    return (sr - hr).abs().mean()
+
+
+def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
+    """10*log10(1/MSE) on [0,1] data (SURVEY.md 8c parity PSNR)."""
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return float("inf") if mse == 0 else 10.0 * math.log10(1.0 / mse)
+
+
+def state_from_numpy(sd_np) -> Dict[str, torch.Tensor]:
+    return {k: torch.from_numpy(v) for k, v in sd_np.items()}

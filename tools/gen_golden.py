@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference model (build container only).
+
+The reference (``/root/reference/model/LFT.py``) is loaded from its own path, filled with the
+deterministic weights of ``lft_amd.params.deterministic_state`` and run on seeded inputs; forward
+hooks capture per-stage activations.  Only data (inputs' seeds, expected outputs, sub-sampled
+activations and their statistics) is written -- no reference source or bytecode leaves the
+container.  The GPU box regenerates inputs and weights from the seeds recorded in each fixture.
+
+Usage:  python tools/gen_golden.py            (needs /root/reference; writes tests/golden/)
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from lft_amd.params import deterministic_state, synthetic_lr  # noqa: E402
+from oracle.fixtures import stats, sub_indices  # noqa: E402
+
+REF_FILE = "/root/reference/model/LFT.py"
+FULL_TAPS = ("feat", "ang0", "spa0", "spa3")  # kept whole on the tiny case only
+
+
+def load_reference():
+    spec = importlib.util.spec_from_file_location("_reference_lft", REF_FILE)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def tap_record(t: torch.Tensor) -> dict:
+    a = t.detach().contiguous().numpy().astype(np.float32).ravel()
+    return {"sub": a[sub_indices(a.size)].copy(), "stats": stats(a)}
+
+
+def run_case(ref, name, A, s, B, h, w, wseed=1, iseed=0, flavor="stress", full_taps=False):
+    sd = deterministic_state(64, s, seed=wseed, flavor=flavor)
+    net = ref.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=s)).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=iseed))
+    taps = {}
+
+    def hook(key):
+        def fn(_m, _i, o):
+            taps[key] = o.detach().clone()
+        return fn
+
+    hs = [net.conv_init0.register_forward_hook(hook("conv0")),
+          net.conv_init.register_forward_hook(hook("conv3")),
+          net.upsampling.register_forward_hook(hook("res"))]
+    for l, blk in enumerate(net.altblock):
+        hs.append(blk.ang_trans.register_forward_hook(hook(f"ang{l}")))
+        hs.append(blk.spa_trans.register_forward_hook(hook(f"spa{l}")))
+    with torch.no_grad():
+        out = net(lr)
+        skip = ref.interpolate(lr, A, scale_factor=s, mode="bicubic")
+    for x in hs:
+        x.remove()
+    taps["feat"] = taps["conv3"] + taps["conv0"]
+    del taps["conv3"]
+    rec = {"meta": np.array([A, s, B, h, w, wseed, iseed], dtype=np.int64),
+           "flavor": np.array(flavor), "out": out.numpy()}
+    taps["skip"] = skip
+    for k, v in taps.items():
+        r = tap_record(v)
+        rec[f"tap_{k}_sub"] = r["sub"]
+        rec[f"tap_{k}_stats"] = r["stats"]
+        if full_taps and k in FULL_TAPS:
+            rec[f"tap_{k}_full"] = v.numpy()
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: out {tuple(out.shape)} rms {float(out.pow(2).mean().sqrt()):.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def misc(ref):
+    """Input-independent pieces: window masks (incl. the h!=w quirk) and position encodings."""
+    rec = {}
+    for (h, w) in [(8, 8), (6, 4), (4, 8)]:
+        m = ref.SpaTrans.gen_mask(h, w, 5).numpy()
+        rec[f"mask_{h}x{w}"] = np.isfinite(m)          # True where attention is allowed
+    pe = ref.PositionEncoding(temperature=10000)
+    dummy = torch.zeros(1, 64, 25, 8, 6)
+    rec["pe_spa_8x6"] = pe(dummy, dim=[3, 4], token_dim=64).numpy()   # [1,64,1,8,6]
+    rec["pe_ang_25"] = pe(dummy, dim=[2], token_dim=64).numpy()       # [1,64,25,1,1]
+    x = torch.from_numpy(synthetic_lr(1, 3, 7, 5, seed=3))
+    for s in (2, 4):
+        rec[f"bicubic_a3_7x5_s{s}"] = ref.interpolate(x, 3, scale_factor=s, mode="bicubic").numpy()
+    # loss
+    a = torch.from_numpy(synthetic_lr(1, 2, 4, 4, seed=5))
+    b = torch.from_numpy(synthetic_lr(1, 2, 4, 4, seed=6))
+    rec["l1_pair"] = np.stack([a.numpy(), b.numpy()])
+    rec["l1_value"] = np.array(float(ref.get_loss(None)(a, b)))
+    path = os.path.join(ROOT, "tests", "golden", "misc.npz")
+    np.savez_compressed(path, **rec)
+    print(f"misc -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main():
+    torch.set_num_threads(8)
+    ref = load_reference()
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    misc(ref)
+    run_case(ref, "tiny_a5_s2_b2_6x6", 5, 2, 2, 6, 6, full_taps=True)       # per-stage activations in full
+    run_case(ref, "small_a5_s4_b1_8x8", 5, 4, 1, 8, 8)
+    run_case(ref, "small_a9_s4_b1_8x8", 9, 4, 1, 8, 8)
+    run_case(ref, "rect_a5_s2_b1_8x6", 5, 2, 1, 8, 6)                       # h > w: still the correct window rule
+    run_case(ref, "cfg1_a5_s2_b1_32x32", 5, 2, 1, 32, 32, flavor="default")   # BASELINE configs[0]
+    run_case(ref, "cfg2_a5_s4_b1_32x32", 5, 4, 1, 32, 32, flavor="default")   # one patch of configs[1]
+
+
+if __name__ == "__main__":
+    main()
