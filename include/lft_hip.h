@@ -1,0 +1,84 @@
+/* lft_hip.h -- C ABI of liblft_hip.so: the LFT forward hot path on MI355X (gfx950).
+ *
+ * This library replaces, for CUDA/HIP tensors, the arithmetic of the reference's
+ *   model/LFT.py:52-83   get_model.forward  (and everything it calls: :86-115, :118-191, :194-238, :255-266)
+ * behind the reference's own plugin surface (model.LFT.get_model(args).forward(lr)); the Python module
+ * lft_amd/module.py binds these entry points with ctypes.  INTEGRATION.md shows the binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and ints; no torch types.  All pointers are DEVICE pointers unless noted.
+ *  - The library never allocates, frees or retains device memory: the caller owns every buffer
+ *    (packed weights, workspace, inputs, outputs) and sizes them with the *_bytes() queries.
+ *  - Every call only enqueues work on `stream` (a hipStream_t passed as void*) and returns without
+ *    synchronising; calls are graph-capturable.
+ *  - Return value: 0 ok; <0 argument error (LFT_ERR_*); >0 a hipError_t.  lft_last_error() gives a
+ *    thread-local message.  Nothing is thrown across the boundary.
+ *  - prec selects the MFMA operand type: LFT_PREC_F32 = exact fp32 (v_mfma_f32_32x32x2_f32),
+ *    LFT_PREC_BF16 = bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16).  Activations between
+ *    kernels are stored in the same type (float or __bf16, channels-last [B, A*A, h, w, C]).
+ *  - Shapes: A = angRes (A*A <= 32 in this version), h x w = LR view size, s = scale factor (2 or 4),
+ *    channels fixed to 64 (reference option.py --channels default, LFT.py:11).
+ */
+#ifndef LFT_HIP_H
+#define LFT_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFT_ABI_VERSION 1
+#define LFT_PREC_F32 0
+#define LFT_PREC_BF16 1
+#define LFT_NUM_PARAMS 78
+
+#define LFT_ERR_ARG (-1)         /* null pointer / bad enum */
+#define LFT_ERR_SHAPE (-2)       /* shape outside what this build supports */
+#define LFT_ERR_UNSUPPORTED (-3) /* valid for the reference, not implemented here yet */
+
+int lft_version(void);
+const char* lft_last_error(void);
+
+/* Size of the packed-weight buffer for a model with (A, h, w, s) and of the per-forward workspace. */
+int lft_packed_bytes(int A, int h, int w, int s, int prec, size_t* out_bytes);
+int lft_workspace_bytes(int B, int A, int h, int w, int s, int prec, size_t* out_bytes);
+
+/* Re-arrange the reference's 78 fp32 parameter tensors (device pointers, in state_dict order -- the
+ * order of lft_amd/params.py:param_table, which is the reference's registration order, LFT.py:23-44,
+ * :125-145, :199-214) into MFMA-fragment streams, and precompute the input-independent tables
+ * (angular / spatial sinusoids LFT.py:86-115, and the embedded spatial position tokens LFT.py:180).
+ * `params` is a HOST array of 78 device pointers.  Must be re-run whenever a weight, h or w changes. */
+int lft_pack_weights(const float* const* params, int nparams, void* packed,
+                     int A, int h, int w, int s, int prec, void* stream);
+
+/* get_model.forward (reference LFT.py:52-83).  lr: fp32 [B,1,A*h,A*w]; out: fp32 [B,1,A*h*s,A*w*s]. */
+int lft_forward(const void* packed, const float* lr, float* out, void* workspace,
+                int B, int A, int h, int w, int s, int prec, void* stream);
+
+/* ---- per-stage entry points (unit tests, profiling).  `act` buffers are channels-last
+ * [B, A*A, h, w, 64] in the activation type of `prec` (float or __bf16). ---- */
+
+/* interpolate(), reference LFT.py:255-266: per-view bicubic of the LR mosaic. */
+int lft_bicubic_fwd(const float* lr, float* out, int B, int A, int h, int w, int s, void* stream);
+/* conv_init0 + conv_init + residual, reference LFT.py:65-66.  Needs the workspace for 3 temporaries. */
+int lft_init_features_fwd(const void* packed, const float* lr, void* act_out, void* workspace,
+                          int B, int A, int h, int w, int s, int prec, void* stream);
+/* AngTrans.forward of layer `layer`, reference LFT.py:225-238. */
+int lft_ang_block_fwd(const void* packed, int layer, const void* act_in, void* act_out,
+                      int B, int A, int h, int w, int s, int prec, void* stream);
+/* SpaTrans.forward of layer `layer`, reference LFT.py:176-191; skip (may be NULL) is added to the
+ * output (the global residual of LFT.py:76 when layer == 3). */
+int lft_spa_block_fwd(const void* packed, int layer, const void* act_in, const void* skip, void* act_out,
+                      void* workspace, int B, int A, int h, int w, int s, int prec, void* stream);
+/* upsampling + bicubic skip, reference LFT.py:79-81: act_in [B,V,h,w,64] -> out fp32 [B,1,A*h*s,A*w*s]. */
+int lft_upsample_fwd(const void* packed, const void* act_in, const float* lr, float* out, void* workspace,
+                     int B, int A, int h, int w, int s, int prec, void* stream);
+/* MFMA fragment-layout self test: C = Am[32x16] * Bm[16x32], D = W2[32x32] * C.  All fp32 device buffers. */
+int lft_mfma_selftest(const float* Am, const float* Bm, const float* W2, float* C, float* D, int prec, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFT_HIP_H */

@@ -1,0 +1,98 @@
+"""ctypes binding of liblft_hip.so (C ABI declared in include/lft_hip.h) and its in-tree build.
+
+The product path has NO CPU fallback: if the library is missing or fails to load, every entry
+point raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` or ``build()`` here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "liblft_hip.so")
+SOURCES = ["lft_api.hip", "lft_common.cuh", "lft_kernels_a.cuh", "lft_kernels_b.cuh"]
+
+PREC_F32, PREC_BF16 = 0, 1
+NUM_PARAMS = 78
+
+_lib = None
+
+
+class LftError(RuntimeError):
+    pass
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", "lft_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc cross-compiles for gfx950 (works without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           os.path.join(CSRC, "lft_api.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise LftError("hipcc failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+_SIGS = {
+    "lft_version": (c_int, []),
+    "lft_last_error": (c_char_p, []),
+    "lft_packed_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "lft_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "lft_pack_weights": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_bicubic_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_init_features_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_ang_block_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_spa_block_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_upsample_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_mfma_selftest": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) the in-tree shared library; raise loudly if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LftError(f"{LIB_PATH} is missing: the HIP extension has not been built "
+                           "(run __graft_entry__.build()); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().lft_last_error()
+        raise LftError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def packed_bytes(A, h, w, s, prec) -> int:
+    n = c_size_t(0)
+    check(lib().lft_packed_bytes(A, h, w, s, prec, ctypes.byref(n)), "lft_packed_bytes")
+    return n.value
+
+
+def workspace_bytes(B, A, h, w, s, prec) -> int:
+    n = c_size_t(0)
+    check(lib().lft_workspace_bytes(B, A, h, w, s, prec, ctypes.byref(n)), "lft_workspace_bytes")
+    return n.value

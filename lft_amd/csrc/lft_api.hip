@@ -1,0 +1,395 @@
+// lft_api.hip -- C ABI of liblft_hip.so (see include/lft_hip.h): buffer layouts, weight packing plan,
+// kernel launches.  Host-side code only enqueues work on the caller's stream.
+#include "../../include/lft_hip.h"
+#include "lft_kernels_a.cuh"
+#include "lft_kernels_b.cuh"
+
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define LFT_HIP_OK(expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail((int)e_, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+#define LFT_LAUNCH_OK(name)                                                                  \
+    do {                                                                                     \
+        hipError_t e_ = hipGetLastError();                                                   \
+        if (e_ != hipSuccess) return fail((int)e_, "launch %s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int kLayers = 4;   // reference LFT.py:15
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Dims {
+    int B, A, V, h, w, hw, s, gp, gt, nchunk;
+    long long ntok;
+};
+
+int make_dims(int B, int A, int h, int w, int s, int prec, Dims* d) {
+    if (prec != LFT_PREC_F32 && prec != LFT_PREC_BF16) return fail(LFT_ERR_ARG, "prec must be LFT_PREC_F32 or LFT_PREC_BF16, got %d", prec);
+    if (B < 1 || A < 1 || h < 1 || w < 1) return fail(LFT_ERR_SHAPE, "B, A, h, w must be positive (B=%d A=%d h=%d w=%d)", B, A, h, w);
+    if (s != 2 && s != 4) return fail(LFT_ERR_SHAPE, "scale factor must be 2 or 4, got %d", s);
+    if (A * A > 32) return fail(LFT_ERR_UNSUPPORTED, "angRes %d (A*A=%d views > 32) is not implemented in this build", A, A * A);
+    if ((long long)B * A * A * h * w > (1LL << 27)) return fail(LFT_ERR_SHAPE, "too many tokens");
+    d->B = B; d->A = A; d->V = A * A; d->h = h; d->w = w; d->hw = h * w; d->s = s;
+    d->gp = (s + 2) * (s + 2); d->gt = (d->gp + 31) / 32; d->nchunk = 2 * s * s;
+    d->ntok = (long long)B * d->V * d->hw;
+    return 0;
+}
+
+// Fragment counts per stream
+constexpr int kFragsConv = 72, kFragsAng = 64, kFragsSpa1 = 240, kFragsSpa2 = 176;
+inline int frags_up(const Dims& d) { return d.nchunk * (4 + 2 * d.gt); }
+
+struct PackedLayout {
+    size_t conv0_w, ln_ang[kLayers], ln_spa[kLayers], ang_pe, petok[kLayers], spa_pe_img;
+    size_t s_conv[3], s_ang[kLayers], s_spa1[kLayers], s_spa2[kLayers], s_up, total;
+};
+
+PackedLayout packed_layout(const Dims& d, int prec) {
+    const size_t esz = prec == LFT_PREC_F32 ? 4 : 2, fragb = 64 * 8 * esz;
+    PackedLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
+    L.conv0_w = take(576 * 4);
+    for (int l = 0; l < kLayers; ++l) { L.ln_ang[l] = take(256 * 4); L.ln_spa[l] = take(512 * 4); }
+    L.ang_pe = take((size_t)d.V * 64 * 4);
+    for (int l = 0; l < kLayers; ++l) L.petok[l] = take((size_t)d.hw * 128 * 4);
+    L.spa_pe_img = take((size_t)d.hw * 64 * esz);
+    for (int i = 0; i < 3; ++i) L.s_conv[i] = take(kFragsConv * fragb);
+    for (int l = 0; l < kLayers; ++l) {
+        L.s_ang[l] = take(kFragsAng * fragb);
+        L.s_spa1[l] = take(kFragsSpa1 * fragb);
+        L.s_spa2[l] = take(kFragsSpa2 * fragb);
+    }
+    L.s_up = take((size_t)frags_up(d) * fragb);
+    L.total = o;
+    return L;
+}
+
+struct WorkLayout {
+    size_t x0, feat, xa, xb, tok, q, k, v, o, g, total;
+};
+WorkLayout work_layout(const Dims& d, int prec) {
+    const size_t esz = prec == LFT_PREC_F32 ? 4 : 2;
+    WorkLayout W;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
+    const size_t n = (size_t)d.ntok;
+    W.x0 = take(n * 64 * esz); W.feat = take(n * 64 * esz); W.xa = take(n * 64 * esz); W.xb = take(n * 64 * esz);
+    W.tok = take(n * 128 * esz); W.q = take(n * 128 * esz); W.k = take(n * 128 * esz); W.v = take(n * 128 * esz);
+    W.o = take(n * 128 * esz);
+    W.g = take(n * d.gp * 4);
+    W.total = o;
+    return W;
+}
+
+template <typename P> P* at(const void* base, size_t off) { return reinterpret_cast<P*>(const_cast<char*>(static_cast<const char*>(base)) + off); }
+inline unsigned blocks_for(long long items, int per_block) { return (unsigned)((items + per_block - 1) / per_block); }
+
+// ---------------------------------------------------------------------------- packing plan
+PackOp lin_op(const float* src, int row0, int nrows, int ld, int k0, int ksteps, int kmap, float scale, int kmul = 1, int kadd = 0) {
+    PackOp p{};
+    p.src = src; p.kind = 0; p.row0 = row0; p.nrows = nrows; p.ntiles = (nrows + 31) / 32; p.ld = ld;
+    p.kmul = kmul; p.kadd = kadd; p.k0 = k0; p.ksteps = ksteps; p.kmap = kmap; p.scale = scale; p.s = 0; p.frag0 = 0;
+    return p;
+}
+void conv_ops(std::vector<PackOp>& v, const float* w, int nout) {   // [nout][64][3][3] == [nout][576], k index c*9 + tap
+    for (int tap = 0; tap < 9; ++tap)
+        for (int ks = 0; ks < 4; ++ks) v.push_back(lin_op(w, 0, nout, 576, 16 * ks, 1, 0, 1.0f, 9, tap));
+}
+
+template <typename T>
+int run_pack(std::vector<PackOp>& ops, T* dst, int expect_frags, hipStream_t st) {
+    int total = 0;
+    size_t i = 0;
+    while (i < ops.size()) {
+        PackArgs a{};
+        int nf = 0;
+        while (i < ops.size() && a.nops < LFT_PACK_MAXOPS) {
+            a.op[a.nops] = ops[i];
+            a.op[a.nops].frag0 = nf;
+            nf += ops[i].ntiles * ops[i].ksteps;
+            ++a.nops; ++i;
+        }
+        k_pack<T><<<nf, 64, 0, st>>>(a, dst + (size_t)total * 512);
+        LFT_LAUNCH_OK("k_pack");
+        total += nf;
+    }
+    if (total != expect_frags) return fail(LFT_ERR_ARG, "internal: stream has %d fragments, expected %d", total, expect_frags);
+    return 0;
+}
+
+template <typename T>
+int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipStream_t st) {
+    const PackedLayout L = packed_layout(d, prec);
+    const float kAngScale = 0.35355339059327373f * LFT_LOG2E;   // 1/sqrt(8) (head_dim 8), exp2 softmax
+    const float kSpaScale = 0.25f * LFT_LOG2E;                   // 1/sqrt(16)
+    int rc;
+    k_copy_f32<<<3, 256, 0, st>>>(P[0], at<float>(packed, L.conv0_w), 576);
+    LFT_LAUNCH_OK("k_copy_f32");
+    for (int i = 0; i < 3; ++i) {
+        std::vector<PackOp> ops;
+        conv_ops(ops, P[1 + i], 64);
+        if ((rc = run_pack<T>(ops, at<T>(packed, L.s_conv[i]), kFragsConv, st))) return rc;
+    }
+    k_pe_tables<T><<<blocks_for((long long)std::max(d.V, d.hw) * 64, 256), 256, 0, st>>>(
+        at<float>(packed, L.ang_pe), at<T>(packed, L.spa_pe_img), d.V, d.h, d.w);
+    LFT_LAUNCH_OK("k_pe_tables");
+    for (int l = 0; l < kLayers; ++l) {
+        const float* const* q = P + 4 + 18 * l;
+        float* lnS = at<float>(packed, L.ln_spa[l]);
+        float* lnA = at<float>(packed, L.ln_ang[l]);
+        const int srcS[4] = {1, 2, 5, 6}, srcA[4] = {10, 11, 14, 15};
+        for (int j = 0; j < 4; ++j) {
+            k_copy_f32<<<1, 256, 0, st>>>(q[srcS[j]], lnS + 128 * j, 128);
+            k_copy_f32<<<1, 256, 0, st>>>(q[srcA[j]], lnA + 64 * j, 64);
+        }
+        LFT_LAUNCH_OK("k_copy_f32");
+        {   // angular stream
+            std::vector<PackOp> ops;
+            ops.push_back(lin_op(q[12], 0, 64, 64, 0, 4, 1, kAngScale));
+            ops.push_back(lin_op(q[12], 64, 64, 64, 0, 4, 1, 1.0f));
+            ops.push_back(lin_op(q[12], 128, 64, 64, 0, 4, 1, 1.0f));
+            ops.push_back(lin_op(q[13], 0, 64, 64, 0, 4, 1, 1.0f));
+            ops.push_back(lin_op(q[16], 0, 128, 64, 0, 4, 1, 1.0f));
+            ops.push_back(lin_op(q[17], 0, 64, 128, 0, 8, 1, 1.0f));
+            if ((rc = run_pack<T>(ops, at<T>(packed, L.s_ang[l]), kFragsAng, st))) return rc;
+        }
+        {   // spatial part 1: token embedding conv + in_proj
+            std::vector<PackOp> ops;
+            conv_ops(ops, q[0], 128);
+            ops.push_back(lin_op(q[3], 0, 128, 128, 0, 8, 1, kSpaScale));
+            ops.push_back(lin_op(q[3], 128, 128, 128, 0, 8, 1, 1.0f));
+            ops.push_back(lin_op(q[3], 256, 128, 128, 0, 8, 1, 1.0f));
+            if ((rc = run_pack<T>(ops, at<T>(packed, L.s_spa1[l]), kFragsSpa1, st))) return rc;
+        }
+        {   // spatial part 2: out_proj (operand from memory: natural k), FFN in 4 chunks, 1x1x1 conv
+            std::vector<PackOp> ops;
+            ops.push_back(lin_op(q[4], 0, 128, 128, 0, 8, 0, 1.0f));
+            for (int c = 0; c < 4; ++c) {
+                ops.push_back(lin_op(q[7], 64 * c, 64, 128, 0, 8, 1, 1.0f));
+                ops.push_back(lin_op(q[8], 0, 128, 256, 64 * c, 4, 1, 1.0f));
+            }
+            ops.push_back(lin_op(q[9], 0, 64, 128, 0, 8, 1, 1.0f));
+            if ((rc = run_pack<T>(ops, at<T>(packed, L.s_spa2[l]), kFragsSpa2, st))) return rc;
+        }
+        // embedded spatial position tokens of this layer (reference LFT.py:180), fp32 [h*w][128]
+        k_spa1<T, true><<<blocks_for((d.hw + 31) / 32, 4), 256, 0, st>>>(
+            at<T>(packed, L.spa_pe_img), at<T>(packed, L.s_spa1[l]), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+            at<float>(packed, L.petok[l]), 1, d.h, d.w);
+        LFT_LAUNCH_OK("k_spa1<pe>");
+    }
+    {   // up-sampler: per 32-row chunk of the 1x1 conv, followed by the matching columns of the overlap-add matrix
+        std::vector<PackOp> ops;
+        for (int c = 0; c < d.nchunk; ++c) {
+            ops.push_back(lin_op(P[76], 32 * c, 32, 64, 0, 4, 1, 1.0f));
+            PackOp m = lin_op(P[77], 0, d.gp, 0, 32 * c, 2, 1, 1.0f);
+            m.kind = 1; m.s = d.s; m.ntiles = d.gt;
+            ops.push_back(m);
+        }
+        if ((rc = run_pack<T>(ops, at<T>(packed, L.s_up), frags_up(d), st))) return rc;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- stages
+template <typename T>
+int init_features(const void* packed, const PackedLayout& L, const float* lr, T* x0, T* ta, T* tb, T* feat, const Dims& d, hipStream_t st) {
+    const int nimg = d.B * d.V, tiles = nimg * ((d.hw + 31) / 32);
+    k_conv0<T><<<blocks_for(d.ntok * 8, 256), 256, 0, st>>>(lr, at<float>(packed, L.conv0_w), x0, d.B, d.A, d.h, d.w);
+    LFT_LAUNCH_OK("k_conv0");
+    k_conv64<T, false><<<blocks_for(tiles, 4), 256, 0, st>>>(x0, ta, nullptr, at<T>(packed, L.s_conv[0]), nimg, d.h, d.w);
+    k_conv64<T, false><<<blocks_for(tiles, 4), 256, 0, st>>>(ta, tb, nullptr, at<T>(packed, L.s_conv[1]), nimg, d.h, d.w);
+    k_conv64<T, true><<<blocks_for(tiles, 4), 256, 0, st>>>(tb, feat, x0, at<T>(packed, L.s_conv[2]), nimg, d.h, d.w);
+    LFT_LAUNCH_OK("k_conv64");
+    return 0;
+}
+template <typename T>
+int ang_block(const void* packed, const PackedLayout& L, int l, const T* in, T* out, const Dims& d, hipStream_t st) {
+    const int npix = d.B * d.hw;
+    k_ang<T><<<blocks_for(npix, 4), 256, 0, st>>>(in, out, at<T>(packed, L.s_ang[l]), at<float>(packed, L.ln_ang[l]),
+                                                   at<float>(packed, L.ang_pe), d.V, d.hw, npix);
+    LFT_LAUNCH_OK("k_ang");
+    return 0;
+}
+template <typename T>
+int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, const T* skip, T* out, void* ws, const WorkLayout& W,
+              const Dims& d, hipStream_t st) {
+    const int nimg = d.B * d.V, tiles = nimg * ((d.hw + 31) / 32);
+    T *tok = at<T>(ws, W.tok), *q = at<T>(ws, W.q), *k = at<T>(ws, W.k), *v = at<T>(ws, W.v), *o = at<T>(ws, W.o);
+    const float* ln = at<float>(packed, L.ln_spa[l]);
+    k_spa1<T, false><<<blocks_for(tiles, 4), 256, 0, st>>>(in, at<T>(packed, L.s_spa1[l]), ln, at<float>(packed, L.petok[l]),
+                                                           tok, q, k, v, nullptr, nimg, d.h, d.w);
+    LFT_LAUNCH_OK("k_spa1");
+    k_spa_attn<T><<<blocks_for(d.ntok * 8, 256), 256, 0, st>>>(q, k, v, o, d.ntok, d.h, d.w);
+    LFT_LAUNCH_OK("k_spa_attn");
+    const unsigned nb = blocks_for((d.ntok + 31) / 32, 4);
+    if (skip) k_spa2<T, true><<<nb, 256, 0, st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.ntok);
+    else k_spa2<T, false><<<nb, 256, 0, st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, nullptr, out, d.ntok);
+    LFT_LAUNCH_OK("k_spa2");
+    return 0;
+}
+template <typename T>
+int upsample(const void* packed, const PackedLayout& L, const T* body, const float* lr, float* out, void* ws, const WorkLayout& W,
+             const Dims& d, hipStream_t st) {
+    float* g = at<float>(ws, W.g);
+    const unsigned nb = blocks_for((d.ntok + 31) / 32, 4);
+    if (d.gt == 1) k_up<T, 1><<<nb, 256, 0, st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
+    else k_up<T, 2><<<nb, 256, 0, st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
+    LFT_LAUNCH_OK("k_up");
+    const long long npx = (long long)d.B * d.A * d.h * d.s * d.A * d.w * d.s;
+    k_assemble<<<blocks_for(npx, 256), 256, 0, st>>>(lr, g, out, d.B, d.A, d.h, d.w, d.s, 1);
+    LFT_LAUNCH_OK("k_assemble");
+    return 0;
+}
+
+template <typename T>
+int forward_impl(const void* packed, const float* lr, float* out, void* ws, const Dims& d, int prec, hipStream_t st) {
+    const PackedLayout L = packed_layout(d, prec);
+    const WorkLayout W = work_layout(d, prec);
+    T *x0 = at<T>(ws, W.x0), *feat = at<T>(ws, W.feat), *xa = at<T>(ws, W.xa), *xb = at<T>(ws, W.xb);
+    int rc;
+    if ((rc = init_features<T>(packed, L, lr, x0, xa, xb, feat, d, st))) return rc;
+    const T* cur = feat;
+    for (int l = 0; l < kLayers; ++l) {                  // angular first, then spatial (reference LFT.py:249-250)
+        if ((rc = ang_block<T>(packed, L, l, cur, xa, d, st))) return rc;
+        if ((rc = spa_block<T>(packed, L, l, xa, l == kLayers - 1 ? feat : nullptr, xb, ws, W, d, st))) return rc;
+        cur = xb;
+    }
+    return upsample<T>(packed, L, xb, lr, out, ws, W, d, st);
+}
+
+}  // namespace
+
+// ================================================================================ C ABI
+extern "C" {
+
+int lft_version(void) { return LFT_ABI_VERSION; }
+const char* lft_last_error(void) { return g_err; }
+
+int lft_packed_bytes(int A, int h, int w, int s, int prec, size_t* out_bytes) {
+    Dims d; int rc;
+    if (!out_bytes) return fail(LFT_ERR_ARG, "out_bytes is null");
+    if ((rc = make_dims(1, A, h, w, s, prec, &d))) return rc;
+    *out_bytes = packed_layout(d, prec).total;
+    return 0;
+}
+int lft_workspace_bytes(int B, int A, int h, int w, int s, int prec, size_t* out_bytes) {
+    Dims d; int rc;
+    if (!out_bytes) return fail(LFT_ERR_ARG, "out_bytes is null");
+    if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
+    *out_bytes = work_layout(d, prec).total;
+    return 0;
+}
+
+int lft_pack_weights(const float* const* params, int nparams, void* packed, int A, int h, int w, int s, int prec, void* stream) {
+    Dims d; int rc;
+    if (!params || !packed) return fail(LFT_ERR_ARG, "null pointer");
+    if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
+    for (int i = 0; i < nparams; ++i)
+        if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
+    if ((rc = make_dims(1, A, h, w, s, prec, &d))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return prec == LFT_PREC_F32 ? pack_impl<float>(params, packed, d, prec, st) : pack_impl<bf16_t>(params, packed, d, prec, st);
+}
+
+int lft_forward(const void* packed, const float* lr, float* out, void* workspace, int B, int A, int h, int w, int s, int prec, void* stream) {
+    Dims d; int rc;
+    if (!packed || !lr || !out || !workspace) return fail(LFT_ERR_ARG, "null pointer");
+    if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return prec == LFT_PREC_F32 ? forward_impl<float>(packed, lr, out, workspace, d, prec, st)
+                                : forward_impl<bf16_t>(packed, lr, out, workspace, d, prec, st);
+}
+
+int lft_bicubic_fwd(const float* lr, float* out, int B, int A, int h, int w, int s, void* stream) {
+    Dims d; int rc;
+    if (!lr || !out) return fail(LFT_ERR_ARG, "null pointer");
+    if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
+    const long long npx = (long long)B * A * h * s * A * w * s;
+    k_assemble<<<blocks_for(npx, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(lr, nullptr, out, B, A, h, w, s, 0);
+    LFT_LAUNCH_OK("k_assemble");
+    return 0;
+}
+
+int lft_init_features_fwd(const void* packed, const float* lr, void* act_out, void* workspace, int B, int A, int h, int w, int s,
+                          int prec, void* stream) {
+    Dims d; int rc;
+    if (!packed || !lr || !act_out || !workspace) return fail(LFT_ERR_ARG, "null pointer");
+    if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
+    const PackedLayout L = packed_layout(d, prec);
+    const WorkLayout W = work_layout(d, prec);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (prec == LFT_PREC_F32)
+        return init_features<float>(packed, L, lr, at<float>(workspace, W.x0), at<float>(workspace, W.xa), at<float>(workspace, W.xb),
+                                    static_cast<float*>(act_out), d, st);
+    return init_features<bf16_t>(packed, L, lr, at<bf16_t>(workspace, W.x0), at<bf16_t>(workspace, W.xa), at<bf16_t>(workspace, W.xb),
+                                 static_cast<bf16_t*>(act_out), d, st);
+}
+
+int lft_ang_block_fwd(const void* packed, int layer, const void* act_in, void* act_out, int B, int A, int h, int w, int s, int prec,
+                      void* stream) {
+    Dims d; int rc;
+    if (!packed || !act_in || !act_out) return fail(LFT_ERR_ARG, "null pointer");
+    if (layer < 0 || layer >= kLayers) return fail(LFT_ERR_ARG, "layer %d out of range", layer);
+    if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
+    const PackedLayout L = packed_layout(d, prec);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (prec == LFT_PREC_F32) return ang_block<float>(packed, L, layer, static_cast<const float*>(act_in), static_cast<float*>(act_out), d, st);
+    return ang_block<bf16_t>(packed, L, layer, static_cast<const bf16_t*>(act_in), static_cast<bf16_t*>(act_out), d, st);
+}
+
+int lft_spa_block_fwd(const void* packed, int layer, const void* act_in, const void* skip, void* act_out, void* workspace, int B, int A,
+                      int h, int w, int s, int prec, void* stream) {
+    Dims d; int rc;
+    if (!packed || !act_in || !act_out || !workspace) return fail(LFT_ERR_ARG, "null pointer");
+    if (layer < 0 || layer >= kLayers) return fail(LFT_ERR_ARG, "layer %d out of range", layer);
+    if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
+    const PackedLayout L = packed_layout(d, prec);
+    const WorkLayout W = work_layout(d, prec);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (prec == LFT_PREC_F32)
+        return spa_block<float>(packed, L, layer, static_cast<const float*>(act_in), static_cast<const float*>(skip),
+                                static_cast<float*>(act_out), workspace, W, d, st);
+    return spa_block<bf16_t>(packed, L, layer, static_cast<const bf16_t*>(act_in), static_cast<const bf16_t*>(skip),
+                             static_cast<bf16_t*>(act_out), workspace, W, d, st);
+}
+
+int lft_upsample_fwd(const void* packed, const void* act_in, const float* lr, float* out, void* workspace, int B, int A, int h, int w,
+                     int s, int prec, void* stream) {
+    Dims d; int rc;
+    if (!packed || !act_in || !lr || !out || !workspace) return fail(LFT_ERR_ARG, "null pointer");
+    if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
+    const PackedLayout L = packed_layout(d, prec);
+    const WorkLayout W = work_layout(d, prec);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (prec == LFT_PREC_F32) return upsample<float>(packed, L, static_cast<const float*>(act_in), lr, out, workspace, W, d, st);
+    return upsample<bf16_t>(packed, L, static_cast<const bf16_t*>(act_in), lr, out, workspace, W, d, st);
+}
+
+int lft_mfma_selftest(const float* Am, const float* Bm, const float* W2, float* C, float* D, int prec, void* stream) {
+    if (!Am || !Bm || !W2 || !C || !D) return fail(LFT_ERR_ARG, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (prec == LFT_PREC_F32) k_selftest<float><<<1, 64, 0, st>>>(Am, Bm, W2, C, D);
+    else if (prec == LFT_PREC_BF16) k_selftest<bf16_t><<<1, 64, 0, st>>>(Am, Bm, W2, C, D);
+    else return fail(LFT_ERR_ARG, "bad prec %d", prec);
+    LFT_LAUNCH_OK("k_selftest");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,224 @@
+// lft_common.cuh -- gfx950 (CDNA4) building blocks shared by every LFT kernel.
+//
+// Design: "token on lane".  A wave owns a tile of 32 tokens; token t sits on MFMA column t
+// (lanes t and t+32).  Every per-token linear layer is computed transposed,
+//     Y^T[n, tok] = sum_k W[n, k] * X^T[k, tok],
+// with the (pre-packed) weight as the MFMA A operand and the activations as the B operand.  The
+// 32x32 accumulator of one product (channel on the row = register index, token on the lane) is,
+// after a register-local down-conversion, directly the B operand of the next product -- so whole
+// chains  LN -> Linear -> ReLU -> Linear -> residual  run in registers with no LDS round trip for
+// activations.  LayerNorm / softmax reductions run over a lane's own registers plus one exchange
+// with lane^32.
+//
+// Two operand precisions share all code:
+//   T = float : v_mfma_f32_32x32x2_f32 (exact fp32, the parity path)
+//   T = bf16  : v_mfma_f32_32x32x16_bf16 (fp32 accumulate, the throughput path)
+// One "k-step" always covers 16 k values; a fragment holds 8 of them per lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define LFT_DEV static __device__ __forceinline__
+
+constexpr int LFT_C = 64;            // feature channels (reference option.py --channels, LFT.py:11)
+constexpr int LFT_E = 128;           // spatial token width 2C (reference LFT.py:124)
+constexpr float LFT_LN_EPS = 1e-5f;  // nn.LayerNorm default
+constexpr float LFT_LOG2E = 1.4426950408889634f;
+
+// ------------------------------------------------------------------------------------------
+// Fragments: 8 k-values per lane of one 16-deep k-step.
+//   lane = 32*h + r.   A operand: A[row r][k(h,j)]   B operand: B[k(h,j)][col r]   j = 0..7
+// For bf16 the hardware fixes k(h,j) = 8h + j inside the instruction; for fp32 we issue 8
+// v_mfma_f32_32x32x2_f32, the j-th consuming element j of both operands (k pair {h=0,h=1}).
+// Any labelling of the 16 k values works as long as A and B agree, which is what lets an
+// accumulator tile be re-used as an operand ("acc order", see acc_to_frag).
+// ------------------------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<float> { f32x4 lo, hi; };
+template <> struct Frag<bf16_t> { bf16x8 v; };
+
+LFT_DEV void mma(const Frag<float>& a, const Frag<float>& b, f32x16& c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[j], b.lo[j], c, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[j], b.hi[j], c, 0, 0, 0);
+}
+LFT_DEV void mma(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
+}
+
+LFT_DEV Frag<float> frag_zero(float) { Frag<float> f; f.lo = f32x4{0, 0, 0, 0}; f.hi = f.lo; return f; }
+LFT_DEV Frag<bf16_t> frag_zero(bf16_t) {
+    Frag<bf16_t> f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = (bf16_t)0.0f;
+    return f;
+}
+// keep elements j<4 (which==0) or j>=4 (which==1); the rest become zero
+LFT_DEV Frag<float> frag_half(const Frag<float>& f, int which) {
+    Frag<float> g = f;
+    if (which == 0) g.hi = f32x4{0, 0, 0, 0}; else g.lo = f32x4{0, 0, 0, 0};
+    return g;
+}
+LFT_DEV Frag<bf16_t> frag_half(const Frag<bf16_t>& f, int which) {
+    Frag<bf16_t> g = f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g.v[which == 0 ? j + 4 : j] = (bf16_t)0.0f;
+    return g;
+}
+template <typename T> LFT_DEV Frag<T> frag_select(bool keep, const Frag<T>& f) { return keep ? f : frag_zero(T()); }
+
+// ------------------------------------------------------------------------------------------
+// Accumulator layout (hardware C/D map of every 32x32 MFMA on gfx950):
+//   element [row][col]:  col = lane & 31,  row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5),  i = 0..15
+// Rows 16s .. 16s+15 (s = 0,1) of a tile are registers 8s .. 8s+7; taken as a fragment they label
+//   k(h, j) = 16 s + 8 (j >> 2) + 4 h + (j & 3)                       ("acc order")
+// and weights consumed against such a fragment are packed with the same labelling.
+// ------------------------------------------------------------------------------------------
+LFT_DEV int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+LFT_DEV Frag<float> acc_to_frag(const f32x16& a, int s, float) {
+    Frag<float> f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.lo[j] = a[8 * s + j]; f.hi[j] = a[8 * s + 4 + j]; }
+    return f;
+}
+LFT_DEV Frag<bf16_t> acc_to_frag(const f32x16& a, int s, bf16_t) {
+    Frag<bf16_t> f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = (bf16_t)a[8 * s + j];
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Packed weight streams: fragment f of a stream occupies 64 * sizeof(Frag<T>) bytes, lane-linear.
+// ------------------------------------------------------------------------------------------
+LFT_DEV Frag<float> load_wfrag(const float* __restrict__ stream, int f, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(stream) + ((size_t)f * 64 + lane) * 2;
+    Frag<float> r; r.lo = p[0]; r.hi = p[1];
+    return r;
+}
+LFT_DEV Frag<bf16_t> load_wfrag(const bf16_t* __restrict__ stream, int f, int lane) {
+    const bf16x8* p = reinterpret_cast<const bf16x8*>(stream) + ((size_t)f * 64 + lane);
+    Frag<bf16_t> r; r.v = *p;
+    return r;
+}
+
+// 8 consecutive channels of a token row in memory -> fragment in NATURAL k order (k = 8h + j);
+// used where an operand comes straight from HBM (conv taps, attention output).
+LFT_DEV Frag<float> load_row8(const float* __restrict__ p, bool ok, float) {
+    Frag<float> r = frag_zero(0.0f);
+    if (ok) { const f32x4* q = reinterpret_cast<const f32x4*>(p); r.lo = q[0]; r.hi = q[1]; }
+    return r;
+}
+LFT_DEV Frag<bf16_t> load_row8(const bf16_t* __restrict__ p, bool ok, bf16_t) {
+    Frag<bf16_t> r = frag_zero(bf16_t());
+    if (ok) r.v = *reinterpret_cast<const bf16x8*>(p);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Token rows <-> accumulator layout.  Token row = NT*32 channels contiguous in memory.
+// Lane (h, r) owns channels 32 nt + 8 g + 4 h + {0..3} (g = 0..3) of token r: 4-channel pieces.
+// ------------------------------------------------------------------------------------------
+LFT_DEV f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+LFT_DEV f32x4 load4(const bf16_t* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+LFT_DEV void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+LFT_DEV void store4(bf16_t* p, f32x4 v) {
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+template <int NT, typename T>
+LFT_DEV void load_acc(const T* __restrict__ row, bool ok, int h, f32x16 (&a)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = f32x4{0, 0, 0, 0};
+            if (ok) v = load4(row + 32 * nt + 8 * g + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[nt][4 * g + j] = v[j];
+        }
+    }
+}
+template <int NT, typename T>
+LFT_DEV void store_acc(T* __restrict__ row, bool ok, int h, const f32x16 (&a)[NT]) {
+    if (!ok) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = f32x4{a[nt][4 * g], a[nt][4 * g + 1], a[nt][4 * g + 2], a[nt][4 * g + 3]};
+            store4(row + 32 * nt + 8 * g + 4 * h, v);
+        }
+    }
+}
+template <int NT>
+LFT_DEV void zero_acc(f32x16 (&a)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[nt][i] = 0.0f;
+}
+
+LFT_DEV float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+LFT_DEV float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+
+// LayerNorm over the NT*32 channels of each token (biased variance, eps inside the sqrt, affine),
+// as nn.LayerNorm does (reference LFT.py:127,136,199,208).  In place.
+template <int NT>
+LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* __restrict__ gamma, const float* __restrict__ beta, int h) {
+    float s = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += a[nt][i];
+    const float mean = xhalf_sum(s) * (1.0f / (NT * 32));
+    float q = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { float d = a[nt][i] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(xhalf_sum(q) * (1.0f / (NT * 32)) + LFT_LN_EPS);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 gm = load4(gamma + 32 * nt + 8 * g + 4 * h);
+            const f32x4 bt = load4(beta + 32 * nt + 8 * g + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[nt][4 * g + j] = (a[nt][4 * g + j] - mean) * rstd * gm[j] + bt[j];
+        }
+}
+
+// all 2*NT k-steps of an accumulator-resident activation as fragments
+template <int NT, typename T>
+LFT_DEV void acc_frags(const f32x16 (&a)[NT], Frag<T> (&f)[2 * NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        f[2 * nt] = acc_to_frag(a[nt], 0, T());
+        f[2 * nt + 1] = acc_to_frag(a[nt], 1, T());
+    }
+}
+
+// Y^T[nt] += sum_ks W(nt, ks) * x[ks]; stream fragments ordered nt-major, starting at f0.
+template <int NT_OUT, int KS, typename T>
+LFT_DEV void linear_acc(const T* __restrict__ w, int f0, int lane, const Frag<T> (&x)[KS], f32x16 (&y)[NT_OUT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT_OUT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) mma(load_wfrag(w, f0 + nt * KS + ks, lane), x[ks], y[nt]);
+}

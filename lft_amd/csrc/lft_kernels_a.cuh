@@ -1,0 +1,248 @@
+// lft_kernels_a.cuh -- weight packing, position tables, initial convolutions, angular Transformer.
+#pragma once
+#include "lft_common.cuh"
+
+// ------------------------------------------------------------------------------------------
+// Weight packing.  A stream is a sequence of fragments in exactly the order a kernel consumes
+// them.  One PackOp describes ntiles x ksteps fragments (nt-major) cut from a row-major fp32 matrix:
+//   frag(nt, ks)[lane = 32h + r][j] = scale * src[(row0 + 32 nt + r) * ld + (k0 + 16 ks + kk(h, j)) * kmul + kadd]
+// kmap 0: natural kk = 8h + j (operand loaded from memory); kmap 1: acc order (see lft_common.cuh).
+// kind 1 (UPM) builds the "overlap-add" matrix of the final 3x3 convolution instead (see k_up).
+// ------------------------------------------------------------------------------------------
+struct PackOp {
+    const float* src;
+    int kind, row0, nrows, ntiles, ld, kmul, kadd, k0, ksteps, kmap, frag0, s;
+    float scale;
+};
+constexpr int LFT_PACK_MAXOPS = 40;
+struct PackArgs {
+    int nops;
+    PackOp op[LFT_PACK_MAXOPS];
+};
+
+// Row n = (I+1)*(s+2) + (J+1), I,J in [-1, s]: HR position relative to the s x s block of one LR pixel.
+// Column kk = c*s*s + i*s + j: PixelShuffle source channel (reference LFT.py:41).  Entry = W3[c][i-I+1][j-J+1]
+// when that tap exists: out[Y] = sum_dy W3[dy+1] F[Y+dy]  (reference LFT.py:43, cross-correlation, pad 1).
+LFT_DEV float upm_entry(const float* __restrict__ w3, int n, int kk, int s) {
+    const int I = n / (s + 2) - 1, J = n % (s + 2) - 1;
+    const int c = kk / (s * s), i = (kk / s) % s, j = kk % s;
+    const int dy = i - I, dx = j - J;
+    if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return 0.0f;
+    return w3[c * 9 + (dy + 1) * 3 + (dx + 1)];
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_pack(PackArgs args, T* __restrict__ dst) {
+    const int f = blockIdx.x, lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    int oi = 0;
+    for (int i = 0; i < args.nops; ++i)
+        if (f >= args.op[i].frag0) oi = i;
+    const PackOp& op = args.op[oi];
+    const int lf = f - op.frag0, nt = lf / op.ksteps, ks = lf % op.ksteps;
+    const int n = 32 * nt + r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kk = op.k0 + 16 * ks + (op.kmap ? 8 * (j >> 2) + 4 * h + (j & 3) : 8 * h + j);
+        float v = 0.0f;
+        if (n < op.nrows) {
+            if (op.kind == 0) v = op.scale * op.src[(size_t)(op.row0 + n) * op.ld + kk * op.kmul + op.kadd];
+            else v = upm_entry(op.src, n, kk, op.s);
+        }
+        dst[((size_t)f * 64 + lane) * 8 + j] = (T)v;
+    }
+}
+
+// Sinusoid position tables (reference LFT.py:91-115): channel c < 32 -> sin(l / T^(2c/64)),
+// c >= 32 -> cos(l / T^(2(c-32)/64)).  Angular table [V][64] fp32; spatial image [h*w][64] = (PE_h[y]+PE_w[x])/2.
+LFT_DEV float pe_value(int l, int c) {
+    const int m = c & 31;
+    const float g = (float)pow(10000.0, (double)(2 * m) / 64.0);
+    const float p = (float)l / g;
+    return (c < 32) ? (float)sin((double)p) : (float)cos((double)p);
+}
+template <typename T>
+__global__ void k_pe_tables(float* __restrict__ ang_pe, T* __restrict__ spa_img, int V, int h, int w) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < V * 64) ang_pe[idx] = pe_value(idx >> 6, idx & 63);
+    if (idx < h * w * 64) {
+        const int p = idx >> 6, c = idx & 63;
+        spa_img[idx] = (T)((pe_value(p / w, c) + pe_value(p % w, c)) / 2.0f);
+    }
+}
+__global__ void k_copy_f32(const float* __restrict__ src, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// conv_init0: 1 -> 64 channels, per-view 3x3, zero pad per view (reference LFT.py:23-25,65).
+// Reads the LR mosaic [B,1,A*h,A*w] (view (a1,a2) is the block at rows a1*h.., cols a2*w.. -- LFT.py:58),
+// writes channels-last tokens [B,V,h,w,64].  One thread = 8 channels of one token.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, const float* __restrict__ w0,
+                                               T* __restrict__ out, int B, int A, int h, int w) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long tok = idx >> 3;
+    const int cg = (int)(idx & 7);
+    const int V = A * A, hw = h * w;
+    if (tok >= (long long)B * V * hw) return;
+    const int p = (int)(tok % hw), v = (int)((tok / hw) % V), b = (int)(tok / ((long long)hw * V));
+    const int y = p / w, x = p % w, a1 = v / A, a2 = v % A;
+    const float* img = lr + (size_t)b * (A * h) * (A * w) + (size_t)(a1 * h) * (A * w) + a2 * w;
+    float val[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        val[t] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[(size_t)yy * (A * w) + xx] : 0.0f;
+    }
+    f32x4 o[2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float a = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a += w0[(cg * 8 + c) * 9 + t] * val[t];
+        o[c >> 2][c & 3] = a;
+    }
+    store4(out + tok * 64 + cg * 8, o[0]);
+    store4(out + tok * 64 + cg * 8 + 4, o[1]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-view 3x3 convolution, 64 -> 32*NT channels, as an implicit GEMM on a 32-token tile:
+// K = 9 taps x 64 channels = 36 k-steps; the B operand of tap (dy,dx) is the neighbour token's
+// channel slice (zero outside the view: per-view padding, reference LFT.py:24,27,167).
+// Stream order: ((tap*4 + ks) * NT + nt).
+// ------------------------------------------------------------------------------------------
+template <int NT, typename T>
+LFT_DEV void conv3x3_tile(const T* __restrict__ img, int y, int x, bool ok, int h, int w, int hh,
+                          const T* __restrict__ wstream, int lane, f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        const bool inb = ok && yy >= 0 && yy < h && xx >= 0 && xx < w;
+        const T* row = img + (size_t)(yy * w + xx) * 64 + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const Frag<T> b = load_row8(row + 16 * ks, inb, T());
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mma(load_wfrag(wstream, (tap * 4 + ks) * NT + nt, lane), b, acc[nt]);
+        }
+    }
+}
+
+// conv_init[i]: 64 -> 64 + LeakyReLU(0.2); the last one adds conv_init0's output (reference LFT.py:26-33,66).
+template <typename T, bool RES>
+__global__ __launch_bounds__(256) void k_conv64(const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ res,
+                                                const T* __restrict__ wstream, int nimg, int h, int w) {
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int hw = h * w, tpi = (hw + 31) >> 5;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= nimg * tpi) return;
+    const int im = tile / tpi, p = (tile % tpi) * 32 + r;
+    const bool ok = p < hw;
+    f32x16 acc[2];
+    zero_acc<2>(acc);
+    conv3x3_tile<2, T>(in + (size_t)im * hw * 64, p / w, p % w, ok, h, w, hh, wstream, lane, acc);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = acc[nt][i] > 0.0f ? acc[nt][i] : 0.2f * acc[nt][i];
+    const size_t off = ((size_t)im * hw + p) * 64;
+    if (RES) {
+        f32x16 rr[2];
+        load_acc<2, T>(res + off, ok, hh, rr);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[nt] += rr[nt];
+    }
+    store_acc<2, T>(out + off, ok, hh, acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// Angular Transformer block, fully fused (reference AngTrans.forward, LFT.py:225-238).
+// One wave = one spatial position (b, y, x); its V <= 32 views sit on the 32 MFMA columns.
+//   n = LN(x + PE_v); Q = n Wq^T, K = n Wk^T (PE'd, normalised) ; V = x Wv^T (raw tokens, LFT.py:230-232)
+//   per head (8 x 8 channels): S^T[kv, q] = K Q^T  -> softmax over kv -> O^T += V^T P^T
+//   t = x + O Wo^T ;  t += W2 relu(W1 LN'(t))
+// Everything stays in registers: Q^T/K^T accumulators are re-used as MFMA operands; V is produced
+// with the operand roles swapped (tokens as A, weight as B) so that it lands view-on-row, which is
+// what the P.V product needs as its A operand.  Heads are separated by zeroing half of a k-step
+// (QK^T: 16 k values = 2 heads) or whole fragments by lane (P.V: 32 output rows = 4 heads).
+// The softmax scale 1/sqrt(8) and log2(e) are folded into the packed Wq; exp2 is used.
+// Stream: Wq[2x4] Wk[2x4] Wv[2x4] Wo[2x4] W1[4x4] W2[2x8]  (64 fragments).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_ang(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ ws,
+                                             const float* __restrict__ ln, const float* __restrict__ pe,
+                                             int V, int hw, int npix) {
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= npix) return;
+    const int b = pix / hw, p = pix % hw;
+    const bool ok = r < V;
+    const size_t off = (((size_t)b * V + r) * hw + p) * 64;
+
+    f32x16 x[2], n[2];
+    load_acc<2, T>(X + off, ok, hh, x);
+    load_acc<2, float>(pe + (size_t)r * 64, ok, hh, n);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) n[nt] += x[nt];
+    layernorm_acc<2>(n, ln, ln + 64, hh);
+    Frag<T> nf[4], xf[4];
+    acc_frags<2, T>(n, nf);
+    acc_frags<2, T>(x, xf);
+
+    f32x16 q[2], k[2], v[2], o[2];
+    zero_acc<2>(q); zero_acc<2>(k); zero_acc<2>(v); zero_acc<2>(o);
+    linear_acc<2, 4, T>(ws, 0, lane, nf, q);
+    linear_acc<2, 4, T>(ws, 8, lane, nf, k);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)           // V[view, ch] = sum_k x[view, k] Wv[ch, k]: tokens are the A operand
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) mma(xf[ks], load_wfrag(ws, 16 + nt * 4 + ks, lane), v[nt]);
+
+#pragma unroll
+    for (int hd = 0; hd < 8; ++hd) {
+        const int nt = hd >> 2, s = (hd >> 1) & 1, half = hd & 1;
+        f32x16 S;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[i] = 0.0f;
+        mma(frag_half(acc_to_frag(k[nt], s, T()), half), acc_to_frag(q[nt], s, T()), S);   // S^T[kv, q]
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (acc_row(i, hh) >= V) S[i] = -INFINITY;
+            m = fmaxf(m, S[i]);
+        }
+        m = xhalf_max(m);
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { S[i] = exp2f(S[i] - m); sum += S[i]; }
+        const float inv = 1.0f / xhalf_sum(sum);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[i] *= inv;
+        const bool mine = (r >> 3) == (hd & 3);          // this lane's channel belongs to head hd
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+            mma(frag_select<T>(mine, acc_to_frag(v[nt], s2, T())), acc_to_frag(S, s2, T()), o[nt]);
+    }
+
+    Frag<T> of[4];
+    acc_frags<2, T>(o, of);
+    linear_acc<2, 4, T>(ws, 24, lane, of, x);              // t = x + O Wo^T
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
+    layernorm_acc<2>(n, ln + 128, ln + 192, hh);
+    acc_frags<2, T>(n, nf);
+    f32x16 hid[4];
+    zero_acc<4>(hid);
+    linear_acc<4, 4, T>(ws, 32, lane, nf, hid);
+    Frag<T> hf[8];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hid[nt][i] = fmaxf(hid[nt][i], 0.0f);
+    acc_frags<4, T>(hid, hf);
+    linear_acc<2, 8, T>(ws, 48, lane, hf, x);
+    store_acc<2, T>(Y + off, ok, hh, x);
+}

@@ -1,0 +1,320 @@
+// lft_kernels_b.cuh -- spatial Transformer (token embedding + QKV, windowed attention, MLP tail),
+// fused up-sampler and the final assemble (overlap-add + bicubic skip).
+#pragma once
+#include "lft_common.cuh"
+#include "lft_kernels_a.cuh"
+
+// ------------------------------------------------------------------------------------------
+// SpaTrans part 1 (reference LFT.py:164-169, 179-186): per 32-token tile of one view image
+//   tok = conv3x3(x; MLP.weight as [128,64,3,3])            (unfold + Linear 576->128)
+//   n   = LN(tok + PEtok[p])                                 (PEtok = same embedding of the position image, cached)
+//   Q = n Wq^T (pre-scaled by 1/4 * log2 e), K = n Wk^T, V = tok Wv^T
+// Stream: conv[36 x 4] Wq[4x8] Wk[4x8] Wv[4x8]  (240 fragments).
+// PE_ONLY: embed the position image itself and write fp32 tokens (pack-time precompute).
+// ------------------------------------------------------------------------------------------
+template <typename T, bool PE_ONLY>
+__global__ __launch_bounds__(256) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
+                                              const float* __restrict__ ln, const float* __restrict__ petok,
+                                              T* __restrict__ TOK, T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vv,
+                                              float* __restrict__ pe_out, int nimg, int h, int w) {
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int hw = h * w, tpi = (hw + 31) >> 5;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= nimg * tpi) return;
+    const int im = tile / tpi, p = (tile % tpi) * 32 + r;
+    const bool ok = p < hw;
+    f32x16 t[4];
+    zero_acc<4>(t);
+    conv3x3_tile<4, T>(X + (size_t)im * hw * 64, p / w, p % w, ok, h, w, hh, ws, lane, t);
+    if (PE_ONLY) {
+        store_acc<4, float>(pe_out + (size_t)p * 128, ok, hh, t);
+        return;
+    }
+    const size_t off = ((size_t)im * hw + p) * 128;
+    store_acc<4, T>(TOK + off, ok, hh, t);
+    f32x16 n[4];
+    load_acc<4, float>(petok + (size_t)p * 128, ok, hh, n);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) n[nt] += t[nt];
+    layernorm_acc<4>(n, ln, ln + 128, hh);
+    Frag<T> nf[8];
+    acc_frags<4, T>(n, nf);
+    {
+        f32x16 a[4];
+        zero_acc<4>(a);
+        linear_acc<4, 8, T>(ws, 144, lane, nf, a);
+        store_acc<4, T>(Q + off, ok, hh, a);
+        zero_acc<4>(a);
+        linear_acc<4, 8, T>(ws, 176, lane, nf, a);
+        store_acc<4, T>(K + off, ok, hh, a);
+    }
+    acc_frags<4, T>(t, nf);
+    zero_acc<4>(n);
+    linear_acc<4, 8, T>(ws, 208, lane, nf, n);
+    store_acc<4, T>(Vv + off, ok, hh, n);
+}
+
+// ------------------------------------------------------------------------------------------
+// SpaTrans windowed attention core (reference LFT.py:147-162 mask + :183-187 attention).
+// One thread = (token, head): 16-dim head, keys = clamped 5x5 window around the query.
+// The reference bounds the window columns by min(h, x+3) (LFT.py:155, "h" where "w" is meant) and
+// slicing clips at w; reproduced as-is: for h < w some queries see no key and come out NaN, as in
+// the reference.  Q is pre-scaled by scale*log2(e); softmax uses exp2.
+// ------------------------------------------------------------------------------------------
+template <typename T> LFT_DEV void load16(const T* p, float (&o)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = load4(p + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[4 * g + j] = v[j];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_spa_attn(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vv,
+                                                  T* __restrict__ O, long long ntok, int h, int w) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long tok = idx >> 3;
+    const int head = (int)(idx & 7);
+    if (tok >= ntok) return;
+    const int hw = h * w;
+    const int p = (int)(tok % hw);
+    const long long img0 = tok - p;
+    const int y = p / w, x = p % w;
+    const int y0 = max(0, y - 2), y1 = min(h, y + 3), x0 = max(0, x - 2), x1 = min(min(h, x + 3), w);
+    float q[16], kv[16], s[25];
+    load16<T>(Q + tok * 128 + head * 16, q);
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
+        s[t] = -INFINITY;
+        if (ky >= y0 && ky < y1 && kx >= x0 && kx < x1) {
+            load16<T>(K + (img0 + ky * w + kx) * 128 + head * 16, kv);
+            float d = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) d += q[c] * kv[c];
+            s[t] = d;
+        }
+        m = fmaxf(m, s[t]);
+    }
+    float sum = 0.0f, o[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) o[c] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
+        if (s[t] != -INFINITY) {
+            const float pr = exp2f(s[t] - m);
+            sum += pr;
+            load16<T>(Vv + (img0 + ky * w + kx) * 128 + head * 16, kv);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) o[c] += pr * kv[c];
+        }
+    }
+    // empty window (only possible for h < w, see above): sum = 0 -> 0 * inf = NaN, as the reference's softmax of all -inf
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        store4(O + tok * 128 + head * 16 + 4 * g, f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv});
+}
+
+// ------------------------------------------------------------------------------------------
+// SpaTrans part 2 (reference LFT.py:187-189, 171-174): per 32-token tile
+//   t  = tok + O Wo^T ;  t2 = t + W2 relu(W1 LN'(t)) ;  y = Wl t2  (Conv3d 1x1x1 128->64)  [+ global skip, LFT.py:76]
+// FFN hidden width 256 is processed in four 64-wide chunks so the hidden activations never leave registers.
+// Stream: Wo[4x8, natural k] {W1c[2x8] W2c[4x4]} x4  Wl[2x8]  (176 fragments).
+// ------------------------------------------------------------------------------------------
+template <typename T, bool SKIP>
+__global__ __launch_bounds__(256) void k_spa2(const T* __restrict__ TOK, const T* __restrict__ O, const T* __restrict__ ws,
+                                              const float* __restrict__ ln, const T* __restrict__ skip, T* __restrict__ Y,
+                                              long long ntok) {
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const long long tok = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + r;
+    if (tok - r >= ntok) return;
+    const bool ok = tok < ntok;
+    f32x16 t[4], n[4];
+    load_acc<4, T>(TOK + tok * 128, ok, hh, t);
+    Frag<T> f[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) f[ks] = load_row8(O + tok * 128 + 16 * ks + 8 * hh, ok, T());
+    linear_acc<4, 8, T>(ws, 0, lane, f, t);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) n[nt] = t[nt];
+    layernorm_acc<4>(n, ln + 256, ln + 384, hh);
+    acc_frags<4, T>(n, f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        f32x16 hid[2];
+        zero_acc<2>(hid);
+        linear_acc<2, 8, T>(ws, 32 + 32 * c, lane, f, hid);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hid[nt][i] = fmaxf(hid[nt][i], 0.0f);
+        Frag<T> hf[4];
+        acc_frags<2, T>(hid, hf);
+        linear_acc<4, 4, T>(ws, 48 + 32 * c, lane, hf, t);
+    }
+    acc_frags<4, T>(t, f);
+    f32x16 y[2];
+    zero_acc<2>(y);
+    linear_acc<2, 8, T>(ws, 160, lane, f, y);
+    if (SKIP) {
+        f32x16 sk[2];
+        load_acc<2, T>(skip + tok * 64, ok, hh, sk);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) y[nt] += sk[nt];
+    }
+    store_acc<2, T>(Y + tok * 64, ok, hh, y);
+}
+
+// ------------------------------------------------------------------------------------------
+// Up-sampler, fused per LR token (reference LFT.py:39-44): never materialises the [B,64,A*h*s,A*w*s] map.
+//   U = Wu x (64 s^2 values) -> LeakyReLU(0.2) -> these are the 64 x s x s HR features of this LR pixel
+//   G = M lrelu(U): the token's contribution to the final 3x3 convolution on the (s+2)x(s+2) HR
+//       neighbourhood of its s x s block ("overlap-add"; M built from upsampling.3.weight by k_pack/UPM).
+// U is produced 32 rows at a time and immediately contracted into G.
+// Stream per chunk c: Wu[1x4] M[GT x 2].  G rows >= (s+2)^2 are padding.
+// ------------------------------------------------------------------------------------------
+template <typename T, int GT>
+__global__ __launch_bounds__(256) void k_up(const T* __restrict__ X, const T* __restrict__ ws, float* __restrict__ G,
+                                            long long ntok, int nchunk, int gp) {
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const long long tok = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + r;
+    if (tok - r >= ntok) return;
+    const bool ok = tok < ntok;
+    f32x16 x[2];
+    load_acc<2, T>(X + tok * 64, ok, hh, x);
+    Frag<T> xf[4];
+    acc_frags<2, T>(x, xf);
+    f32x16 g[GT];
+    zero_acc<GT>(g);
+#pragma unroll 2
+    for (int c = 0; c < nchunk; ++c) {
+        f32x16 u[1];
+        zero_acc<1>(u);
+        linear_acc<1, 4, T>(ws, c * (4 + 2 * GT), lane, xf, u);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) u[0][i] = u[0][i] > 0.0f ? u[0][i] : 0.2f * u[0][i];
+        Frag<T> uf[2];
+        acc_frags<1, T>(u, uf);
+        linear_acc<GT, 2, T>(ws, c * (4 + 2 * GT) + 4, lane, uf, g);
+    }
+    if (!ok) return;
+#pragma unroll
+    for (int nt = 0; nt < GT; ++nt)
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int base = 32 * nt + 8 * grp + 4 * hh;
+            if (base < gp)
+                store4(G + tok * gp + base, f32x4{g[nt][4 * grp], g[nt][4 * grp + 1], g[nt][4 * grp + 2], g[nt][4 * grp + 3]});
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// Assemble (reference LFT.py:43 border handling, :81 skip add, :255-266 bicubic):
+//   out[b, Y, X] = bicubic(lr)[Y, X] + sum over the <= 4 LR mosaic pixels whose (s+2)^2 footprint covers (Y, X)
+// The 3x3 conv runs over the whole mosaic: footprints cross view borders, only the outer mosaic border pads.
+// Bicubic is per view: source = (dst + 0.5)/s - 0.5, taps floor-1..floor+2 clamped to the view, Keys A = -0.75
+// (torch upsample_bicubic2d, align_corners=False).
+// ------------------------------------------------------------------------------------------
+LFT_DEV void cubic_coef(float t, float (&c)[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = 2.0f - t;
+    c[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    c[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+    c[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    c[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+LFT_DEV float bicubic_at(const float* __restrict__ view, int stride, int h, int w, int Y, int X, int s) {
+    const float sy = ((float)Y + 0.5f) / (float)s - 0.5f, sx = ((float)X + 0.5f) / (float)s - 0.5f;
+    const float fy = floorf(sy), fx = floorf(sx);
+    float cy[4], cx[4];
+    cubic_coef(sy - fy, cy);
+    cubic_coef(sx - fx, cx);
+    const int iy = (int)fy, ix = (int)fx;
+    float acc = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = min(max(iy - 1 + a, 0), h - 1);
+        float row = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) row += cx[b] * view[(size_t)yy * stride + min(max(ix - 1 + b, 0), w - 1)];
+        acc += cy[a] * row;
+    }
+    return acc;
+}
+__global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ lr, const float* __restrict__ G, float* __restrict__ out,
+                                                  int B, int A, int h, int w, int s, int with_body) {
+    const int HR_H = A * h * s, HR_W = A * w * s;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * HR_H * HR_W) return;
+    const int X = (int)(idx % HR_W), Y = (int)((idx / HR_W) % HR_H), b = (int)(idx / ((long long)HR_W * HR_H));
+    const int a1 = Y / (h * s), a2 = X / (w * s);
+    const float* view = lr + (size_t)b * (A * h) * (A * w) + (size_t)(a1 * h) * (A * w) + a2 * w;
+    float v = bicubic_at(view, A * w, h, w, Y - a1 * h * s, X - a2 * w * s, s);
+    if (with_body) {
+        const int gp = (s + 2) * (s + 2), hw = h * w, V = A * A;
+        const int qy = Y / s, qx = X / s, i = Y % s, j = X % s;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int I = i - s * dy, J = j - s * dx, by = qy + dy, bx = qx + dx;
+                if (I < -1 || I > s || J < -1 || J > s || by < 0 || by >= A * h || bx < 0 || bx >= A * w) continue;
+                const int vv = (by / h) * A + bx / w, pp = (by % h) * w + bx % w;
+                v += G[(((size_t)b * V + vv) * hw + pp) * gp + (I + 1) * (s + 2) + (J + 1)];
+            }
+    }
+    out[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA layout self-test: C[32x32] = A[32x16] * B[16x32] through the same fragment helpers the
+// kernels use (natural k order), and the acc-order re-use path D = W2 * C.  Checked from Python
+// with asymmetric integer data (guide rule: never validate a layout with symmetric operands).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void k_selftest(const float* __restrict__ Am, const float* __restrict__ Bm,
+                                                 const float* __restrict__ W2, float* __restrict__ Cout, float* __restrict__ Dout) {
+    const int lane = threadIdx.x, r = lane & 31, hh = lane >> 5;
+    Frag<T> a, b;
+    float ta[8], tb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ta[j] = Am[r * 16 + 8 * hh + j]; tb[j] = Bm[(8 * hh + j) * 32 + r]; }
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a.lo[j] = ta[j]; a.hi[j] = ta[4 + j]; b.lo[j] = tb[j]; b.hi[j] = tb[4 + j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a.v[j] = (T)ta[j]; b.v[j] = (T)tb[j]; }
+    }
+    f32x16 c[1];
+    zero_acc<1>(c);
+    mma(a, b, c[0]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Cout[acc_row(i, hh) * 32 + r] = c[0][i];
+    // D[32x32] = W2[32x32] * C, with W2 fragments built in acc order on the fly
+    Frag<T> cf[2];
+    acc_frags<1, T>(c, cf);
+    f32x16 d;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        Frag<T> wf;
+        float tw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tw[j] = W2[r * 32 + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)];
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wf.lo[j] = tw[j]; wf.hi[j] = tw[4 + j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wf.v[j] = (T)tw[j];
+        }
+        mma(wf, cf[s], d);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Dout[acc_row(i, hh) * 32 + r] = d[i];
+}

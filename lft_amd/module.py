@@ -1,0 +1,141 @@
+"""Host-side mirror of the reference plugin surface (reference model/LFT.py:8, :269, :280):
+``get_model(args)`` / ``get_loss(args)`` / ``weights_init(m)``, with the reference's 78 state-dict
+keys, whose ``forward`` runs entirely in liblft_hip.so on the input's HIP device.
+
+PyTorch is used here only for device memory, streams and the nn.Module/state_dict plumbing the
+reference's train.py / test.py expect (load_state_dict, .to(device), .eval(), net(x)).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .params import param_table
+
+_PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "float32": _lib.PREC_F32,
+         "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16}
+
+
+class _Node(nn.Module):
+    """Parameter container; gives state-dict paths like ``altblock.0.spa_trans.MLP.weight``."""
+
+
+def _attach(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
+    parts = dotted.split(".")
+    node = root
+    for name in parts[:-1]:
+        if name not in node._modules:
+            node.add_module(name, _Node())
+        node = node._modules[name]
+    node.register_parameter(parts[-1], p)
+
+
+class get_model(nn.Module):
+    """LFT network (reference model/LFT.py:8-83).  ``args`` needs ``channels`` (64), ``angRes``,
+    ``scale_factor`` exactly as the reference reads them (LFT.py:11-14).
+
+    ``precision``: 'fp32' (exact-fp32 MFMA; parity path, default) or 'bf16' (bf16 MFMA operands,
+    fp32 accumulation).  May also be given as ``args.lft_precision``.
+    """
+
+    def __init__(self, args, precision: Optional[str] = None):
+        super().__init__()
+        self.channels = int(args.channels)
+        self.angRes = int(args.angRes)
+        self.factor = int(args.scale_factor)
+        if self.channels != 64:
+            raise ValueError("this build supports channels=64 only (reference default)")
+        self.precision = precision or getattr(args, "lft_precision", "fp32")
+        if self.precision not in _PREC:
+            raise ValueError(f"unknown precision {self.precision!r}")
+        self._names = []
+        for name, shape, kind in param_table(self.channels, self.factor):
+            t = torch.empty(shape, dtype=torch.float32)
+            if kind.startswith("w"):                       # PyTorch default Conv/Linear init and the explicit
+                b = 1.0 / math.sqrt(int(kind[1:]))         # kaiming_uniform_(a=sqrt(5)) of LFT.py:132,204
+                t.uniform_(-b, b)
+            elif kind == "ln_w":
+                t.fill_(1.0)
+            else:
+                t.zero_()
+            _attach(self, name, nn.Parameter(t))
+            self._names.append(name)
+        self._packed = None        # (key, tensor)
+        self._work = None          # (key, tensor)
+
+    # ------------------------------------------------------------------ packing / buffers
+    def _params_in_order(self):
+        d = dict(self.named_parameters())
+        return [d[n] for n in self._names]
+
+    def _pack_key(self, ps, h, w, prec):
+        return (h, w, prec, tuple((p.data_ptr(), p._version) for p in ps))
+
+    def _ensure_packed(self, dev, h, w, prec, stream):
+        ps = self._params_in_order()
+        for p in ps:
+            if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.LftError("all parameters must be contiguous float32 tensors on the input's device "
+                                    f"({dev}); call net.to(device) first")
+        key = self._pack_key(ps, h, w, prec)
+        if self._packed is None or self._packed[0] != key:
+            nbytes = _lib.packed_bytes(self.angRes, h, w, self.factor, prec)
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            arr = (ctypes.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
+            _lib.check(_lib.lib().lft_pack_weights(arr, len(ps), buf.data_ptr(), self.angRes, h, w, self.factor,
+                                                   prec, stream), "lft_pack_weights")
+            self._packed = (key, buf)
+        return self._packed[1]
+
+    def _ensure_work(self, dev, B, h, w, prec):
+        key = (str(dev), B, h, w, prec)
+        if self._work is None or self._work[0] != key:
+            nbytes = _lib.workspace_bytes(B, self.angRes, h, w, self.factor, prec)
+            self._work = (key, torch.empty(nbytes, dtype=torch.uint8, device=dev))
+        return self._work[1]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, lr: torch.Tensor) -> torch.Tensor:
+        """lr: float32 [B,1,A*h,A*w] on a HIP device -> float32 [B,1,A*h*s,A*w*s] (reference LFT.py:52-83)."""
+        if lr.dim() != 4 or lr.size(1) != 1:
+            raise ValueError(f"expected [B,1,A*h,A*w], got {tuple(lr.shape)}")
+        if not lr.is_cuda:
+            raise _lib.LftError("lft_amd runs on a HIP device only (no CPU fallback); move the input and the model to 'cuda'")
+        if torch.is_grad_enabled() and (lr.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise _lib.LftError("backward is not implemented in this build: call under torch.no_grad() "
+                                "(training path is listed as 'next' in DESIGN.md)")
+        A, s = self.angRes, self.factor
+        B, _, H, W = lr.shape
+        if H % A or W % A:
+            raise ValueError(f"mosaic {H}x{W} is not divisible by angRes {A}")
+        h, w = H // A, W // A
+        x = lr.contiguous().float()
+        prec = _PREC[self.precision]
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            packed = self._ensure_packed(x.device, h, w, prec, stream)
+            work = self._ensure_work(x.device, B, h, w, prec)
+            out = torch.empty((B, 1, H * s, W * s), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().lft_forward(packed.data_ptr(), x.data_ptr(), out.data_ptr(), work.data_ptr(),
+                                              B, A, h, w, s, prec, stream), "lft_forward")
+        return out
+
+
+class get_loss(nn.Module):
+    """Mean absolute error between SR and HR mosaics (reference model/LFT.py:269-277)."""
+
+    def __init__(self, args=None):
+        super().__init__()
+
+    def forward(self, SR, HR):
+        return (SR - HR).abs().mean()
+
+
+def weights_init(m):
+    """No-op, as in the reference (model/LFT.py:280-282); drivers call ``net.apply(weights_init)``."""
+    return None
