@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the LFT forward hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): LFT 5x5 angRes, 4x SR, 32x32 LR patches, batch 4 per GPU, bf16 MFMA
+operands with fp32 accumulation; synthetic U[0,1) inputs and seeded default-init weights; inputs resident
+in HBM before the timed region.  A "step" is one forward over the batch.  Multi-GPU = independent
+data-parallel shards (weak scaling, no data-path collective); one process per GPU, launched by
+torch.distributed.run, barrier + synchronize on both sides of the timed region, max over ranks.
+
+Prints ONE JSON line on rank 0 with the extra objects
+  roofline     : the dominant kernel's algorithmic FLOP/s (HIP events on the launch stream, inside this run)
+                 against the dense bf16 MFMA peak (2.5 PFLOP/s; fp32 path: 157.3 TFLOP/s)
+  cpu_baseline : the CPU oracle (a port of the reference's operator sequence, oracle/lft_oracle.py) timed on
+                 this node's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+A, S, H, W = 5, 4, 32, 32          # BASELINE.json metric: 5x5 angRes, 32x32 LR, 4x SR
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+
+
+def flops_per_token(s: int, V: int, wbar: float) -> dict:
+    """Algorithmic FLOPs (2*MAC) per token and kernel, SURVEY.md 8(d): window-limited attention,
+    LN/softmax/activations excluded, position-token embedding excluded (cached)."""
+    C, E = 64, 128
+    return {
+        "k_conv0": 18 * C,
+        "k_conv64": 18 * C * C,
+        "k_ang": 16 * C * C + 4 * V * C,
+        "k_spa1": 18 * C * E + 6 * E * E,
+        "k_spa_attn": 4 * wbar * E,
+        "k_spa2": 2 * E * E + 8 * E * E + 2 * E * C,
+        "k_up": 2 * C * C * s * s + 18 * C * s * s,
+        "k_assemble": 32 * s * s,
+    }
+
+
+def mean_window(h: int, w: int) -> float:
+    cnt = lambda n: sum(min(n, i + 3) - max(0, i - 2) for i in range(n))  # noqa: E731
+    return cnt(h) * cnt(w) / (h * w)
+
+
+def kernel_breakdown(net, lr, reps: int):
+    """Per-kernel mean milliseconds per launch via lft_forward_profiled (HIP events on torch's current stream)."""
+    from lft_amd import _lib
+    from lft_amd.module import _PREC
+    B = lr.shape[0]
+    prec = _PREC[net.precision]
+    stream = torch.cuda.current_stream().cuda_stream
+    packed = net._ensure_packed(lr.device, H, W, prec, stream)
+    work = net._ensure_work(lr.device, B, H, W, prec)
+    out = torch.empty((B, 1, A * H * S, A * W * S), dtype=torch.float32, device=lr.device)
+    n_max = 64
+    ms = (ctypes.c_float * n_max)()
+    names = (ctypes.c_char_p * n_max)()
+    n = ctypes.c_int(0)
+    acc = {}
+    for _ in range(reps):
+        _lib.check(_lib.lib().lft_forward_profiled(packed.data_ptr(), lr.data_ptr(), out.data_ptr(), work.data_ptr(),
+                                                   B, A, H, W, S, prec, stream, n_max, ms, names, ctypes.byref(n)),
+                   "lft_forward_profiled")
+        for i in range(n.value):
+            k = names[i].decode()
+            t, c = acc.get(k, (0.0, 0))
+            acc[k] = (t + ms[i], c + 1)
+    return {k: (t / c, c // reps) for k, (t, c) in acc.items()}     # name -> (mean ms per launch, launches per forward)
+
+
+def cpu_baseline(seconds: float):
+    from lft_amd.params import deterministic_state, synthetic_lr
+    from oracle import lft_oracle as O            # the checker, timed as the CPU baseline
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = O.state_from_numpy(deterministic_state(64, S, seed=1))
+    lr = torch.from_numpy(synthetic_lr(1, A, H, W, seed=0))
+    O.forward(sd, lr, A, S)                        # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.forward(sd, lr, A, S)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 64:
+            break
+    return {"value": n / dt, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} single-patch forwards (A5, 4x, 32x32 LR, fp32, torch {torch.__version__} CPU ops) in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4, help="LF patches per GPU per step (BASELINE configs[1]: 4)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from lft_amd.params import deterministic_state, synthetic_lr
+    from model import LFT
+    net = LFT.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=S), precision=args.precision)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in deterministic_state(64, S, seed=1).items()})
+    net = net.to(dev).eval()
+    lr = torch.from_numpy(synthetic_lr(args.batch, A, H, W, seed=rank)).to(dev)   # resident in HBM
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = net(lr)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net(lr)
+        sync()
+        dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(out).all())
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = None
+    if rank == 0:
+        V = A * A
+        ntok = args.batch * V * H * W
+        fpt = flops_per_token(S, V, mean_window(H, W))
+        with torch.no_grad():
+            kb = kernel_breakdown(net, lr, reps=10)
+        total_ms = sum(ms * cnt for ms, cnt in kb.values())
+        dom = max(kb, key=lambda k: kb[k][0] * kb[k][1])
+        dom_ms, dom_cnt = kb[dom]
+        units = args.batch * A * H * S * A * W * S if dom == "k_assemble" else ntok
+        achieved = fpt[dom] * units / (dom_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        flops_patch = sum(fpt[k] * (V * H * W) * c for k, (_, c) in kb.items() if k != "k_assemble") + fpt["k_assemble"] * (V * H * W)
+        result = {
+            "metric": "LF patches/sec (5x5 angRes, 32x32 LR, 4xSR)",
+            "value": world * args.batch * args.steps / dt,
+            "unit": "patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"LFT 5x5 angRes 4xSR inference, batch={args.batch} per GPU, 32x32 LR patches",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world} (independent shards)",
+                       "algorithmic_gflop_per_patch": flops_patch / 1e9},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "launch_ms": dom_ms, "launches_per_forward": dom_cnt, "gpu_ms_per_forward": total_ms,
+                         "kernels": {k: {"ms": round(ms, 4), "n": c, "tflops": round(fpt[k] * (units if k == dom else (args.batch * A * H * S * A * W * S if k == "k_assemble" else ntok)) / (ms * 1e-3) / 1e12, 2)}
+                                     for k, (ms, c) in kb.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,13 @@ int lft_pack_weights(const float* const* params, int nparams, void* packed,
 int lft_forward(const void* packed, const float* lr, float* out, void* workspace,
                 int B, int A, int h, int w, int s, int prec, void* stream);
 
+/* Profiling aid, NOT for the hot path: same as lft_forward but records a HIP event on `stream` after every
+ * kernel, SYNCHRONISES the stream, and returns per-kernel milliseconds (host arrays ms_out / names_out of
+ * max_records entries; names are static strings).  bench.py uses it for the roofline of the dominant kernel. */
+int lft_forward_profiled(const void* packed, const float* lr, float* out, void* workspace,
+                         int B, int A, int h, int w, int s, int prec, void* stream,
+                         int max_records, float* ms_out, const char** names_out, int* n_out);
+
 /* ---- per-stage entry points (unit tests, profiling).  `act` buffers are channels-last
  * [B, A*A, h, w, 64] in the activation type of `prec` (float or __bf16). ---- */
 

@@ -55,6 +55,8 @@ _SIGS = {
     "lft_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "lft_pack_weights": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lft_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_forward_profiled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_int, POINTER(c_float), POINTER(c_char_p), POINTER(c_int)]),
     "lft_bicubic_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lft_init_features_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lft_ang_block_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

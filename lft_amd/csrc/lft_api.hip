@@ -25,10 +25,28 @@ int fail(int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                              \
         if (e_ != hipSuccess) return fail((int)e_, "%s: %s", #expr, hipGetErrorString(e_));   \
     } while (0)
+// Optional per-kernel timing (lft_forward_profiled): an event is recorded on the launch stream after each kernel.
+struct Profiler {
+    bool on = false;
+    hipStream_t st = nullptr;
+    std::vector<hipEvent_t> ev;
+    std::vector<const char*> names;
+};
+thread_local Profiler g_prof;
+inline void prof_mark(const char* name) {
+    if (!g_prof.on) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    hipEventRecord(e, g_prof.st);
+    g_prof.ev.push_back(e);
+    g_prof.names.push_back(name);
+}
+
 #define LFT_LAUNCH_OK(name)                                                                  \
     do {                                                                                     \
         hipError_t e_ = hipGetLastError();                                                   \
         if (e_ != hipSuccess) return fail((int)e_, "launch %s: %s", name, hipGetErrorString(e_)); \
+        prof_mark(name);                                                                     \
     } while (0)
 
 constexpr int kLayers = 4;   // reference LFT.py:15
@@ -214,7 +232,9 @@ int init_features(const void* packed, const PackedLayout& L, const float* lr, T*
     k_conv0<T><<<blocks_for(d.ntok * 8, 256), 256, 0, st>>>(lr, at<float>(packed, L.conv0_w), x0, d.B, d.A, d.h, d.w);
     LFT_LAUNCH_OK("k_conv0");
     k_conv64<T, false><<<blocks_for(tiles, 4), 256, 0, st>>>(x0, ta, nullptr, at<T>(packed, L.s_conv[0]), nimg, d.h, d.w);
+    LFT_LAUNCH_OK("k_conv64");
     k_conv64<T, false><<<blocks_for(tiles, 4), 256, 0, st>>>(ta, tb, nullptr, at<T>(packed, L.s_conv[1]), nimg, d.h, d.w);
+    LFT_LAUNCH_OK("k_conv64");
     k_conv64<T, true><<<blocks_for(tiles, 4), 256, 0, st>>>(tb, feat, x0, at<T>(packed, L.s_conv[2]), nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_conv64");
     return 0;
@@ -315,6 +335,30 @@ int lft_forward(const void* packed, const float* lr, float* out, void* workspace
     hipStream_t st = static_cast<hipStream_t>(stream);
     return prec == LFT_PREC_F32 ? forward_impl<float>(packed, lr, out, workspace, d, prec, st)
                                 : forward_impl<bf16_t>(packed, lr, out, workspace, d, prec, st);
+}
+
+int lft_forward_profiled(const void* packed, const float* lr, float* out, void* workspace, int B, int A, int h, int w, int s, int prec,
+                         void* stream, int max_records, float* ms_out, const char** names_out, int* n_out) {
+    if (!ms_out || !names_out || !n_out) return fail(LFT_ERR_ARG, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    g_prof.on = true; g_prof.st = st; g_prof.ev.clear(); g_prof.names.clear();
+    prof_mark("start");
+    int rc = lft_forward(packed, lr, out, workspace, B, A, h, w, s, prec, stream);
+    g_prof.on = false;
+    hipError_t e = hipStreamSynchronize(st);
+    int n = 0;
+    for (size_t i = 1; i < g_prof.ev.size() && n < max_records; ++i, ++n) {
+        float ms = 0.0f;
+        hipEventElapsedTime(&ms, g_prof.ev[i - 1], g_prof.ev[i]);
+        ms_out[n] = ms;
+        names_out[n] = g_prof.names[i];
+    }
+    for (hipEvent_t ev : g_prof.ev) hipEventDestroy(ev);
+    g_prof.ev.clear(); g_prof.names.clear();
+    *n_out = n;
+    if (rc) return rc;
+    if (e != hipSuccess) return fail((int)e, "hipStreamSynchronize: %s", hipGetErrorString(e));
+    return 0;
 }
 
 int lft_bicubic_fwd(const float* lr, float* out, int B, int A, int h, int w, int s, void* stream) {
