@@ -82,7 +82,8 @@ def kernel_breakdown(net, lr, reps: int):
 def cpu_baseline(seconds: float):
     from lft_amd.params import deterministic_state, synthetic_lr
     from oracle import lft_oracle as O            # the checker, timed as the CPU baseline
-    cores = os.cpu_count() or 1
+    # threads = this process's CPU share (the GPU box gives 16 CPUs per GPU; os.cpu_count() reports the whole host)
+    cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("LFT_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     sd = O.state_from_numpy(deterministic_state(64, S, seed=1))
     lr = torch.from_numpy(synthetic_lr(1, A, H, W, seed=0))
@@ -96,6 +97,10 @@ def cpu_baseline(seconds: float):
             break
     return {"value": n / dt, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} single-patch forwards (A5, 4x, 32x32 LR, fp32, torch {torch.__version__} CPU ops) in {dt:.1f} s"}
+
+
+def note(msg: str) -> None:
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -135,6 +140,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note(f"rank {rank}/{world}: model on {dev}, precision {args.precision}, batch {args.batch}")
     with torch.no_grad():
         for _ in range(args.warmup):
             out = net(lr)
@@ -145,6 +151,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
     assert bool(torch.isfinite(out).all())
+    note(f"rank {rank}: {args.steps} steps in {dt:.3f} s")
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -158,6 +165,7 @@ def main():
         with torch.no_grad():
             kb = kernel_breakdown(net, lr, reps=10)
         total_ms = sum(ms * cnt for ms, cnt in kb.values())
+        note("kernel ms/launch: " + ", ".join(f"{k}={ms:.3f}x{c}" for k, (ms, c) in kb.items()))
         dom = max(kb, key=lambda k: kb[k][0] * kb[k][1])
         dom_ms, dom_cnt = kb[dom]
         units = args.batch * A * H * S * A * W * S if dom == "k_assemble" else ntok
@@ -182,6 +190,7 @@ def main():
                                      for k, (ms, c) in kb.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
+            note("timing the CPU oracle on host cores ...")
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(result), flush=True)
     if dist is not None:
