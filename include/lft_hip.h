@@ -82,6 +82,9 @@ int lft_spa_block_fwd(const void* packed, int layer, const void* act_in, const v
 /* upsampling + bicubic skip, reference LFT.py:79-81: act_in [B,V,h,w,64] -> out fp32 [B,1,A*h*s,A*w*s]. */
 int lft_upsample_fwd(const void* packed, const void* act_in, const float* lr, float* out, void* workspace,
                      int B, int A, int h, int w, int s, int prec, void* stream);
+/* Debug aid: a single conv_init[which] launch (with_res: add `res`; extra_lds: pad the LDS request). */
+int lft_debug_conv64(const void* packed, int which, int with_res, const void* in, const void* res, void* out,
+                     int B, int A, int h, int w, int s, int prec, int extra_lds, void* stream);
 /* MFMA fragment-layout self test: C = Am[32x16] * Bm[16x32], D = W2[32x32] * C.  All fp32 device buffers. */
 int lft_mfma_selftest(const float* Am, const float* Bm, const float* W2, float* C, float* D, int prec, void* stream);
 

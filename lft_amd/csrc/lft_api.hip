@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -37,7 +38,7 @@ inline void prof_mark(const char* name) {
     if (!g_prof.on) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
-    hipEventRecord(e, g_prof.st);
+    (void)hipEventRecord(e, g_prof.st);
     g_prof.ev.push_back(e);
     g_prof.names.push_back(name);
 }
@@ -114,6 +115,18 @@ WorkLayout work_layout(const Dims& d, int prec) {
     W.g = take(n * d.gp * 4);
     W.total = o;
     return W;
+}
+
+// Dynamic LDS sizes (bytes) and the opt-in above the 64 KiB default (a workgroup may use all 160 KiB of a CU).
+template <typename T> size_t lds_conv64(int w) { return WRing<T, kConv64Chunk>::LDS_BYTES + ConvIn<T>::bytes(w); }
+template <typename T> size_t lds_spa1(int w) { return WRing<T, kSpaChunk>::LDS_BYTES + ConvIn<T>::bytes(w); }
+template <typename T> size_t lds_ring() { return WRing<T, kSpaChunk>::LDS_BYTES; }
+template <typename T> size_t lds_ang() { return (size_t)kFragsAng * 1024 * FragInfo<T>::PIECES; }
+constexpr size_t kMaxLds = 160 * 1024;
+template <typename K> int allow_lds(K kernel, size_t bytes, const char* name) {
+    if (bytes > kMaxLds) return fail(LFT_ERR_SHAPE, "%s needs %zu B of LDS (> 160 KiB): view width too large for this build", name, bytes);
+    if (bytes > 64 * 1024) LFT_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
 }
 
 template <typename P> P* at(const void* base, size_t off) { return reinterpret_cast<P*>(const_cast<char*>(static_cast<const char*>(base)) + off); }
@@ -207,7 +220,8 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
             if ((rc = run_pack<T>(ops, at<T>(packed, L.s_spa2[l]), kFragsSpa2, st))) return rc;
         }
         // embedded spatial position tokens of this layer (reference LFT.py:180), fp32 [h*w][128]
-        k_spa1<T, true><<<blocks_for((d.hw + 31) / 32, 4), 256, 0, st>>>(
+        if ((rc = allow_lds(k_spa1<T, true>, lds_spa1<T>(d.w), "k_spa1"))) return rc;
+        k_spa1<T, true><<<(d.hw + 127) / 128, 256, lds_spa1<T>(d.w), st>>>(
             at<T>(packed, L.spa_pe_img), at<T>(packed, L.s_spa1[l]), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
             at<float>(packed, L.petok[l]), 1, d.h, d.w);
         LFT_LAUNCH_OK("k_spa1<pe>");
@@ -228,21 +242,29 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
 // ---------------------------------------------------------------------------- stages
 template <typename T>
 int init_features(const void* packed, const PackedLayout& L, const float* lr, T* x0, T* ta, T* tb, T* feat, const Dims& d, hipStream_t st) {
-    const int nimg = d.B * d.V, tiles = nimg * ((d.hw + 31) / 32);
+    const int nimg = d.B * d.V, nwg = nimg * ((d.hw + 127) / 128);
+    const size_t lds = lds_conv64<T>(d.w);
+    int rc;
+    if ((rc = allow_lds(k_conv64<T, false>, lds, "k_conv64"))) return rc;
+    if ((rc = allow_lds(k_conv64<T, true>, lds, "k_conv64"))) return rc;
     k_conv0<T><<<blocks_for(d.ntok * 8, 256), 256, 0, st>>>(lr, at<float>(packed, L.conv0_w), x0, d.B, d.A, d.h, d.w);
     LFT_LAUNCH_OK("k_conv0");
-    k_conv64<T, false><<<blocks_for(tiles, 4), 256, 0, st>>>(x0, ta, nullptr, at<T>(packed, L.s_conv[0]), nimg, d.h, d.w);
+    k_conv64<T, false><<<nwg, 256, lds, st>>>(x0, ta, nullptr, at<T>(packed, L.s_conv[0]), nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_conv64");
-    k_conv64<T, false><<<blocks_for(tiles, 4), 256, 0, st>>>(ta, tb, nullptr, at<T>(packed, L.s_conv[1]), nimg, d.h, d.w);
+    k_conv64<T, false><<<nwg, 256, lds, st>>>(ta, tb, nullptr, at<T>(packed, L.s_conv[1]), nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_conv64");
-    k_conv64<T, true><<<blocks_for(tiles, 4), 256, 0, st>>>(tb, feat, x0, at<T>(packed, L.s_conv[2]), nimg, d.h, d.w);
+    k_conv64<T, true><<<nwg, 256, lds, st>>>(tb, feat, x0, at<T>(packed, L.s_conv[2]), nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_conv64");
     return 0;
 }
 template <typename T>
 int ang_block(const void* packed, const PackedLayout& L, int l, const T* in, T* out, const Dims& d, hipStream_t st) {
     const int npix = d.B * d.hw;
-    k_ang<T><<<blocks_for(npix, 4), 256, 0, st>>>(in, out, at<T>(packed, L.s_ang[l]), at<float>(packed, L.ln_ang[l]),
+    const size_t lds = lds_ang<T>();
+    int rc;
+    if ((rc = allow_lds(k_ang<T>, lds, "k_ang"))) return rc;
+    const unsigned grid = std::min<unsigned>(blocks_for(npix, 4), 256u * (unsigned)std::max<size_t>(1, kMaxLds / lds));
+    k_ang<T><<<grid, 256, lds, st>>>(in, out, at<T>(packed, L.s_ang[l]), at<float>(packed, L.ln_ang[l]),
                                                    at<float>(packed, L.ang_pe), d.V, d.hw, npix);
     LFT_LAUNCH_OK("k_ang");
     return 0;
@@ -250,17 +272,21 @@ int ang_block(const void* packed, const PackedLayout& L, int l, const T* in, T* 
 template <typename T>
 int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, const T* skip, T* out, void* ws, const WorkLayout& W,
               const Dims& d, hipStream_t st) {
-    const int nimg = d.B * d.V, tiles = nimg * ((d.hw + 31) / 32);
+    const int nimg = d.B * d.V, nwg = nimg * ((d.hw + 127) / 128);
     T *tok = at<T>(ws, W.tok), *q = at<T>(ws, W.q), *k = at<T>(ws, W.k), *v = at<T>(ws, W.v), *o = at<T>(ws, W.o);
     const float* ln = at<float>(packed, L.ln_spa[l]);
-    k_spa1<T, false><<<blocks_for(tiles, 4), 256, 0, st>>>(in, at<T>(packed, L.s_spa1[l]), ln, at<float>(packed, L.petok[l]),
-                                                           tok, q, k, v, nullptr, nimg, d.h, d.w);
+    int rc;
+    if ((rc = allow_lds(k_spa1<T, false>, lds_spa1<T>(d.w), "k_spa1"))) return rc;
+    k_spa1<T, false><<<nwg, 256, lds_spa1<T>(d.w), st>>>(in, at<T>(packed, L.s_spa1[l]), ln, at<float>(packed, L.petok[l]),
+                                                         tok, q, k, v, nullptr, nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_spa1");
     k_spa_attn<T><<<blocks_for(d.ntok * 8, 256), 256, 0, st>>>(q, k, v, o, d.ntok, d.h, d.w);
     LFT_LAUNCH_OK("k_spa_attn");
-    const unsigned nb = blocks_for((d.ntok + 31) / 32, 4);
-    if (skip) k_spa2<T, true><<<nb, 256, 0, st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.ntok);
-    else k_spa2<T, false><<<nb, 256, 0, st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, nullptr, out, d.ntok);
+    const unsigned nb = blocks_for(d.ntok, 128);
+    if ((rc = allow_lds(k_spa2<T, true>, lds_ring<T>(), "k_spa2"))) return rc;
+    if ((rc = allow_lds(k_spa2<T, false>, lds_ring<T>(), "k_spa2"))) return rc;
+    if (skip) k_spa2<T, true><<<nb, 256, lds_ring<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.ntok);
+    else k_spa2<T, false><<<nb, 256, lds_ring<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, nullptr, out, d.ntok);
     LFT_LAUNCH_OK("k_spa2");
     return 0;
 }
@@ -268,9 +294,12 @@ template <typename T>
 int upsample(const void* packed, const PackedLayout& L, const T* body, const float* lr, float* out, void* ws, const WorkLayout& W,
              const Dims& d, hipStream_t st) {
     float* g = at<float>(ws, W.g);
-    const unsigned nb = blocks_for((d.ntok + 31) / 32, 4);
-    if (d.gt == 1) k_up<T, 1><<<nb, 256, 0, st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
-    else k_up<T, 2><<<nb, 256, 0, st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
+    const unsigned nb = blocks_for(d.ntok, 128);
+    int rc;
+    if ((rc = allow_lds(k_up<T, 1>, lds_ring<T>(), "k_up"))) return rc;
+    if ((rc = allow_lds(k_up<T, 2>, lds_ring<T>(), "k_up"))) return rc;
+    if (d.gt == 1) k_up<T, 1><<<nb, 256, lds_ring<T>(), st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
+    else k_up<T, 2><<<nb, 256, lds_ring<T>(), st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
     LFT_LAUNCH_OK("k_up");
     const long long npx = (long long)d.B * d.A * d.h * d.s * d.A * d.w * d.s;
     k_assemble<<<blocks_for(npx, 256), 256, 0, st>>>(lr, g, out, d.B, d.A, d.h, d.w, d.s, 1);
@@ -349,11 +378,11 @@ int lft_forward_profiled(const void* packed, const float* lr, float* out, void* 
     int n = 0;
     for (size_t i = 1; i < g_prof.ev.size() && n < max_records; ++i, ++n) {
         float ms = 0.0f;
-        hipEventElapsedTime(&ms, g_prof.ev[i - 1], g_prof.ev[i]);
+        (void)hipEventElapsedTime(&ms, g_prof.ev[i - 1], g_prof.ev[i]);
         ms_out[n] = ms;
         names_out[n] = g_prof.names[i];
     }
-    for (hipEvent_t ev : g_prof.ev) hipEventDestroy(ev);
+    for (hipEvent_t ev : g_prof.ev) (void)hipEventDestroy(ev);
     g_prof.ev.clear(); g_prof.names.clear();
     *n_out = n;
     if (rc) return rc;
@@ -424,6 +453,33 @@ int lft_upsample_fwd(const void* packed, const void* act_in, const float* lr, fl
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (prec == LFT_PREC_F32) return upsample<float>(packed, L, static_cast<const float*>(act_in), lr, out, workspace, W, d, st);
     return upsample<bf16_t>(packed, L, static_cast<const bf16_t*>(act_in), lr, out, workspace, W, d, st);
+}
+
+// Debug aid (tools/stress_conv.py): one k_conv64 launch. which = 0..2 selects the weight stream, with_res the variant,
+// extra_lds pads the dynamic LDS request (e.g. to force one workgroup per CU).
+int lft_debug_conv64(const void* packed, int which, int with_res, const void* in, const void* res, void* out, int B, int A, int h,
+                     int w, int s, int prec, int extra_lds, void* stream) {
+    Dims d; int rc;
+    if (!packed || !in || !out || which < 0 || which > 2) return fail(LFT_ERR_ARG, "bad argument");
+    if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
+    const PackedLayout L = packed_layout(d, prec);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nimg = d.B * d.V, nwg = nimg * ((d.hw + 127) / 128);
+    if (prec == LFT_PREC_F32) {
+        const size_t lds = lds_conv64<float>(d.w) + extra_lds;
+        if ((rc = allow_lds(k_conv64<float, false>, lds, "k_conv64"))) return rc;
+        if ((rc = allow_lds(k_conv64<float, true>, lds, "k_conv64"))) return rc;
+        if (with_res) k_conv64<float, true><<<nwg, 256, lds, st>>>((const float*)in, (float*)out, (const float*)res, at<float>(packed, L.s_conv[which]), nimg, d.h, d.w);
+        else k_conv64<float, false><<<nwg, 256, lds, st>>>((const float*)in, (float*)out, nullptr, at<float>(packed, L.s_conv[which]), nimg, d.h, d.w);
+    } else {
+        const size_t lds = lds_conv64<bf16_t>(d.w) + extra_lds;
+        if ((rc = allow_lds(k_conv64<bf16_t, false>, lds, "k_conv64"))) return rc;
+        if ((rc = allow_lds(k_conv64<bf16_t, true>, lds, "k_conv64"))) return rc;
+        if (with_res) k_conv64<bf16_t, true><<<nwg, 256, lds, st>>>((const bf16_t*)in, (bf16_t*)out, (const bf16_t*)res, at<bf16_t>(packed, L.s_conv[which]), nimg, d.h, d.w);
+        else k_conv64<bf16_t, false><<<nwg, 256, lds, st>>>((const bf16_t*)in, (bf16_t*)out, nullptr, at<bf16_t>(packed, L.s_conv[which]), nimg, d.h, d.w);
+    }
+    LFT_LAUNCH_OK("k_conv64");
+    return 0;
 }
 
 int lft_mfma_selftest(const float* Am, const float* Bm, const float* W2, float* C, float* D, int prec, void* stream) {

@@ -24,8 +24,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// Raw 16-byte moves (LDS staging, fragment reads) go through a may_alias type, so that type-based alias
+// analysis can never treat an LDS store and a differently-typed LDS load of the same bytes as independent.
+typedef unsigned int raw16 __attribute__((ext_vector_type(4), may_alias));
 
 #define LFT_DEV static __device__ __forceinline__
+#define LFT_MEM __device__ __forceinline__
 
 constexpr int LFT_C = 64;            // feature channels (reference option.py --channels, LFT.py:11)
 constexpr int LFT_E = 128;           // spatial token width 2C (reference LFT.py:124)
@@ -98,18 +102,79 @@ LFT_DEV Frag<bf16_t> acc_to_frag(const f32x16& a, int s, bf16_t) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Packed weight streams: fragment f of a stream occupies 64 * sizeof(Frag<T>) bytes, lane-linear.
+// Packed weight streams.  A stream is a sequence of 1 KiB "pieces", each lane-linear (lane l owns bytes
+// 16 l .. 16 l + 15) -- exactly what one wave-wide global_load_lds_dwordx4 moves.  A bf16 fragment is one
+// piece (8 bf16 per lane); an fp32 fragment is two pieces (elements 0-3, then elements 4-7).
 // ------------------------------------------------------------------------------------------
-LFT_DEV Frag<float> load_wfrag(const float* __restrict__ stream, int f, int lane) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(stream) + ((size_t)f * 64 + lane) * 2;
-    Frag<float> r; r.lo = p[0]; r.hi = p[1];
+template <typename T> struct FragInfo;
+template <> struct FragInfo<float> { static constexpr int PIECES = 2; };
+template <> struct FragInfo<bf16_t> { static constexpr int PIECES = 1; };
+
+LFT_DEV raw16 load_raw16(const char* p) { return *reinterpret_cast<const raw16*>(p); }
+LFT_DEV void store_raw16(char* p, raw16 v) { *reinterpret_cast<raw16*>(p) = v; }
+
+LFT_DEV Frag<float> frag_from_pieces(const char* base, int lane, float) {
+    Frag<float> r;
+    r.lo = __builtin_bit_cast(f32x4, load_raw16(base + lane * 16));
+    r.hi = __builtin_bit_cast(f32x4, load_raw16(base + 1024 + lane * 16));
     return r;
 }
-LFT_DEV Frag<bf16_t> load_wfrag(const bf16_t* __restrict__ stream, int f, int lane) {
-    const bf16x8* p = reinterpret_cast<const bf16x8*>(stream) + ((size_t)f * 64 + lane);
-    Frag<bf16_t> r; r.v = *p;
+LFT_DEV Frag<bf16_t> frag_from_pieces(const char* base, int lane, bf16_t) {
+    Frag<bf16_t> r;
+    r.v = __builtin_bit_cast(bf16x8, load_raw16(base + lane * 16));
     return r;
 }
+template <typename T> LFT_DEV Frag<T> load_wfrag(const T* __restrict__ stream, int f, int lane) {
+    return frag_from_pieces(reinterpret_cast<const char*>(stream) + (size_t)f * 1024 * FragInfo<T>::PIECES, lane, T());
+}
+
+// Asynchronous global -> LDS copy of one 1 KiB piece by one wave (LDS-DMA, no VGPR staging).
+// The LDS destination is wave-uniform (M0) + 16 * lane; the global source is per lane.
+LFT_DEV void glds_piece(const char* __restrict__ gsrc, char* lds_dst, int lane) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + lane * 16),
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// Weight ring: the 4 waves of a workgroup consume the same fragment stream in lock-step.  The stream is
+// cut into chunks of CH fragments; chunk c+1 is DMA'd into the other half of a 2-slot LDS ring while
+// chunk c feeds the MFMAs.  next() must be called by all 256 threads at the same program points (it
+// contains the workgroup barrier that publishes a chunk and retires the previous one).
+template <typename T, int CH>
+struct WRing {
+    static constexpr int FRAG_BYTES = 1024 * FragInfo<T>::PIECES;
+    static constexpr int CHUNK_BYTES = CH * FRAG_BYTES;
+    static constexpr int LDS_BYTES = 2 * CHUNK_BYTES;
+    static constexpr int PIECES_PER_WAVE = CH * FragInfo<T>::PIECES / 4;
+    static_assert((CH * FragInfo<T>::PIECES) % 4 == 0, "chunk must split over 4 waves");
+    const char* g;
+    char* lds;
+    int lane, wave, pos, nfrag;
+    LFT_MEM void init(const T* stream, char* lds_base, int total_frags) {
+        g = reinterpret_cast<const char*>(stream); lds = lds_base; nfrag = total_frags; pos = 0;
+        lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        issue(0);
+    }
+    LFT_MEM void issue(int c) {
+        const char* src = g + (size_t)c * CHUNK_BYTES;
+        char* dst = lds + (c & 1) * CHUNK_BYTES;
+        const int left = (nfrag - c * CH) * FragInfo<T>::PIECES;       // pieces that exist in this chunk
+#pragma unroll
+        for (int i = 0; i < PIECES_PER_WAVE; ++i) {
+            const int piece = wave * PIECES_PER_WAVE + i;
+            if (piece < left) glds_piece(src + piece * 1024, dst + piece * 1024, lane);
+        }
+    }
+    LFT_MEM Frag<T> next() {
+        const int c = pos / CH, i = pos % CH;
+        if (i == 0) {
+            __syncthreads();                                   // chunk c has landed (vmcnt(0) + barrier); chunk c-1 retired
+            if ((c + 1) * CH < nfrag) issue(c + 1);
+        }
+        ++pos;
+        return frag_from_pieces(lds + (c & 1) * CHUNK_BYTES + i * FRAG_BYTES, lane, T());
+    }
+};
 
 // 8 consecutive channels of a token row in memory -> fragment in NATURAL k order (k = 8h + j);
 // used where an operand comes straight from HBM (conv taps, attention output).
@@ -121,6 +186,21 @@ LFT_DEV Frag<float> load_row8(const float* __restrict__ p, bool ok, float) {
 LFT_DEV Frag<bf16_t> load_row8(const bf16_t* __restrict__ p, bool ok, bf16_t) {
     Frag<bf16_t> r = frag_zero(bf16_t());
     if (ok) r.v = *reinterpret_cast<const bf16x8*>(p);
+    return r;
+}
+
+// same from LDS (always in bounds; caller zeroes by predicate)
+LFT_DEV Frag<float> lds_row8(const char* p, bool ok, float) {
+    Frag<float> r;
+    r.lo = __builtin_bit_cast(f32x4, load_raw16(p));
+    r.hi = __builtin_bit_cast(f32x4, load_raw16(p + 16));
+    if (!ok) r = frag_zero(0.0f);
+    return r;
+}
+LFT_DEV Frag<bf16_t> lds_row8(const char* p, bool ok, bf16_t) {
+    Frag<bf16_t> r;
+    r.v = __builtin_bit_cast(bf16x8, load_raw16(p));
+    if (!ok) r = frag_zero(bf16_t());
     return r;
 }
 
@@ -212,6 +292,15 @@ LFT_DEV void acc_frags(const f32x16 (&a)[NT], Frag<T> (&f)[2 * NT]) {
         f[2 * nt] = acc_to_frag(a[nt], 0, T());
         f[2 * nt + 1] = acc_to_frag(a[nt], 1, T());
     }
+}
+
+// Same, weights taken in stream order from the workgroup's LDS ring.
+template <int NT_OUT, int KS, typename T, int CH>
+LFT_DEV void linear_ring(WRing<T, CH>& ring, const Frag<T> (&x)[KS], f32x16 (&y)[NT_OUT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT_OUT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) mma(ring.next(), x[ks], y[nt]);
 }
 
 // Y^T[nt] += sum_ks W(nt, ks) * x[ks]; stream fragments ordered nt-major, starting at f0.

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(64) void k_pack(PackArgs args, T* __restrict__ dst)
             if (op.kind == 0) v = op.scale * op.src[(size_t)(op.row0 + n) * op.ld + kk * op.kmul + op.kadd];
             else v = upm_entry(op.src, n, kk, op.s);
         }
-        dst[((size_t)f * 64 + lane) * 8 + j] = (T)v;
+        if constexpr (sizeof(T) == 4) dst[(((size_t)f * 2 + (j >> 2)) * 64 + lane) * 4 + (j & 3)] = (T)v;   // two 1 KiB pieces
+        else dst[((size_t)f * 64 + lane) * 8 + j] = (T)v;
     }
 }
 
@@ -109,41 +110,72 @@ __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, con
 }
 
 // ------------------------------------------------------------------------------------------
-// Per-view 3x3 convolution, 64 -> 32*NT channels, as an implicit GEMM on a 32-token tile:
-// K = 9 taps x 64 channels = 36 k-steps; the B operand of tap (dy,dx) is the neighbour token's
-// channel slice (zero outside the view: per-view padding, reference LFT.py:24,27,167).
-// Stream order: ((tap*4 + ks) * NT + nt).
+// Per-view 3x3 convolution, 64 -> 32*NT channels, as an implicit GEMM.  A workgroup owns 128
+// consecutive tokens of one view image (4 waves x 32 tokens); K = 9 taps x 64 channels = 36 k-steps.
+//  * input: the 128 tokens plus a halo of w+1 tokens on either side are staged ONCE into LDS (each
+//    token row is re-read by up to 9 taps); rows are padded by 16 B so the per-lane 16-byte reads of
+//    32 different token rows spread over all 64 banks.  Tokens outside the image are staged as zeros;
+//    the left/right image border is handled by the lane predicate (per-view zero padding,
+//    reference LFT.py:24,27,167).
+//  * weights: the fragment stream ((tap*4 + ks) * NT + nt) arrives through the workgroup's LDS ring.
 // ------------------------------------------------------------------------------------------
-template <int NT, typename T>
-LFT_DEV void conv3x3_tile(const T* __restrict__ img, int y, int x, bool ok, int h, int w, int hh,
-                          const T* __restrict__ wstream, int lane, f32x16 (&acc)[NT]) {
+template <typename T> struct ConvIn {
+    static constexpr int ROW_BYTES = 64 * (int)sizeof(T) + 16;
+    static constexpr int PPR = 64 * (int)sizeof(T) / 16;            // 16-byte pieces per token row
+    static __host__ __device__ int slots(int w) { return 130 + 2 * w; }
+    static __host__ __device__ int bytes(int w) { return slots(w) * ROW_BYTES; }
+};
+
+template <typename T>
+LFT_DEV void stage_conv_input(const T* __restrict__ img, int p0, int hw, int w, char* lds_in) {
+    const int n = ConvIn<T>::slots(w) * ConvIn<T>::PPR;
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        const int slot = idx / ConvIn<T>::PPR, piece = idx % ConvIn<T>::PPR;
+        const int q = p0 - w - 1 + slot;
+        raw16 v = raw16{0u, 0u, 0u, 0u};
+        if (q >= 0 && q < hw) v = load_raw16(reinterpret_cast<const char*>(img) + ((size_t)q * 64 * sizeof(T) + piece * 16));
+        store_raw16(lds_in + slot * ConvIn<T>::ROW_BYTES + piece * 16, v);
+    }
+    __syncthreads();   // publish the tile: conv3x3_tile reads a B fragment BEFORE its first ring.next() barrier
+}
+
+// tl = token index inside the workgroup tile (0..127); (y, x) its image coordinates.
+template <int NT, typename T, int CH>
+LFT_DEV void conv3x3_tile(const char* lds_in, int tl, int y, int x, bool ok, int h, int w, int hh,
+                          WRing<T, CH>& ring, f32x16 (&acc)[NT]) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int yy = y + dy, xx = x + dx;
         const bool inb = ok && yy >= 0 && yy < h && xx >= 0 && xx < w;
-        const T* row = img + (size_t)(yy * w + xx) * 64 + 8 * hh;
+        const char* row = lds_in + (tl + w + 1 + dy * w + dx) * ConvIn<T>::ROW_BYTES + 8 * hh * (int)sizeof(T);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const Frag<T> b = load_row8(row + 16 * ks, inb, T());
+            const Frag<T> b = lds_row8(row + 16 * ks * (int)sizeof(T), inb, T());
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) mma(load_wfrag(wstream, (tap * 4 + ks) * NT + nt, lane), b, acc[nt]);
+            for (int nt = 0; nt < NT; ++nt) mma(ring.next(), b, acc[nt]);
         }
     }
 }
 
 // conv_init[i]: 64 -> 64 + LeakyReLU(0.2); the last one adds conv_init0's output (reference LFT.py:26-33,66).
+constexpr int kConv64Chunk = 24;   // 72 fragments = 3 chunks of 3 taps
 template <typename T, bool RES>
 __global__ __launch_bounds__(256) void k_conv64(const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ res,
                                                 const T* __restrict__ wstream, int nimg, int h, int w) {
-    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const int hw = h * w, tpi = (hw + 31) >> 5;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= nimg * tpi) return;
-    const int im = tile / tpi, p = (tile % tpi) * 32 + r;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5, wave = threadIdx.x >> 6;
+    const int hw = h * w, tpi = (hw + 127) >> 7;
+    const int im = blockIdx.x / tpi, p0 = (blockIdx.x % tpi) * 128;
+    const int tl = wave * 32 + r, p = p0 + tl;
     const bool ok = p < hw;
+    char* lds_in = smem + WRing<T, kConv64Chunk>::LDS_BYTES;
+    WRing<T, kConv64Chunk> ring;
+    ring.init(wstream, smem, 72);
+    stage_conv_input<T>(in + (size_t)im * hw * 64, p0, hw, w, lds_in);
     f32x16 acc[2];
     zero_acc<2>(acc);
-    conv3x3_tile<2, T>(in + (size_t)im * hw * 64, p / w, p % w, ok, h, w, hh, wstream, lane, acc);
+    conv3x3_tile<2, T>(lds_in, tl, p / w, p % w, ok, h, w, hh, ring, acc);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -169,80 +201,103 @@ __global__ __launch_bounds__(256) void k_conv64(const T* __restrict__ in, T* __r
 // what the P.V product needs as its A operand.  Heads are separated by zeroing half of a k-step
 // (QK^T: 16 k values = 2 heads) or whole fragments by lane (P.V: 32 output rows = 4 heads).
 // The softmax scale 1/sqrt(8) and log2(e) are folded into the packed Wq; exp2 is used.
-// Stream: Wq[2x4] Wk[2x4] Wv[2x4] Wo[2x4] W1[4x4] W2[2x8]  (64 fragments).
+// Stream: Wq[2x4] Wk[2x4] Wv[2x4] Wo[2x4] W1[4x4] W2[2x8]  (64 fragments) -- small enough to live
+// in LDS for the whole kernel: a persistent workgroup DMAs it once and then walks over positions.
 // ------------------------------------------------------------------------------------------
+template <int NT_OUT, int KS, typename T>
+LFT_DEV void linear_lds(const char* wl, int f0, int lane, const Frag<T> (&x)[KS], f32x16 (&y)[NT_OUT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT_OUT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            mma(frag_from_pieces(wl + (f0 + nt * KS + ks) * 1024 * FragInfo<T>::PIECES, lane, T()), x[ks], y[nt]);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_ang(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ ws,
                                              const float* __restrict__ ln, const float* __restrict__ pe,
                                              int V, int hw, int npix) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int FB = 1024 * FragInfo<T>::PIECES;
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pix >= npix) return;
-    const int b = pix / hw, p = pix % hw;
-    const bool ok = r < V;
-    const size_t off = (((size_t)b * V + r) * hw + p) * 64;
-
-    f32x16 x[2], n[2];
-    load_acc<2, T>(X + off, ok, hh, x);
-    load_acc<2, float>(pe + (size_t)r * 64, ok, hh, n);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {
+        const char* g = reinterpret_cast<const char*>(ws);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) n[nt] += x[nt];
-    layernorm_acc<2>(n, ln, ln + 64, hh);
-    Frag<T> nf[4], xf[4];
-    acc_frags<2, T>(n, nf);
-    acc_frags<2, T>(x, xf);
-
-    f32x16 q[2], k[2], v[2], o[2];
-    zero_acc<2>(q); zero_acc<2>(k); zero_acc<2>(v); zero_acc<2>(o);
-    linear_acc<2, 4, T>(ws, 0, lane, nf, q);
-    linear_acc<2, 4, T>(ws, 8, lane, nf, k);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)           // V[view, ch] = sum_k x[view, k] Wv[ch, k]: tokens are the A operand
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) mma(xf[ks], load_wfrag(ws, 16 + nt * 4 + ks, lane), v[nt]);
-
-#pragma unroll
-    for (int hd = 0; hd < 8; ++hd) {
-        const int nt = hd >> 2, s = (hd >> 1) & 1, half = hd & 1;
-        f32x16 S;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) S[i] = 0.0f;
-        mma(frag_half(acc_to_frag(k[nt], s, T()), half), acc_to_frag(q[nt], s, T()), S);   // S^T[kv, q]
-        float m = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (acc_row(i, hh) >= V) S[i] = -INFINITY;
-            m = fmaxf(m, S[i]);
+        for (int i = 0; i < 16 * FragInfo<T>::PIECES; ++i) {
+            const int piece = wave * 16 * FragInfo<T>::PIECES + i;
+            glds_piece(g + piece * 1024, smem + piece * 1024, lane);
         }
-        m = xhalf_max(m);
-        float sum = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { S[i] = exp2f(S[i] - m); sum += S[i]; }
-        const float inv = 1.0f / xhalf_sum(sum);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) S[i] *= inv;
-        const bool mine = (r >> 3) == (hd & 3);          // this lane's channel belongs to head hd
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-            mma(frag_select<T>(mine, acc_to_frag(v[nt], s2, T())), acc_to_frag(S, s2, T()), o[nt]);
     }
+    __syncthreads();
+    const bool ok = r < V;
+    for (int pix = blockIdx.x * 4 + wave; pix < npix; pix += gridDim.x * 4) {
+        asm volatile("" ::: "memory");    // keep the (loop-invariant) LDS weight reads inside the loop: hoisted, they cost 256+ VGPRs
+        const int b = pix / hw, p = pix % hw;
+        const size_t off = (((size_t)b * V + r) * hw + p) * 64;
 
-    Frag<T> of[4];
-    acc_frags<2, T>(o, of);
-    linear_acc<2, 4, T>(ws, 24, lane, of, x);              // t = x + O Wo^T
+        f32x16 x[2], n[2];
+        load_acc<2, T>(X + off, ok, hh, x);
+        load_acc<2, float>(pe + (size_t)r * 64, ok, hh, n);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
-    layernorm_acc<2>(n, ln + 128, ln + 192, hh);
-    acc_frags<2, T>(n, nf);
-    f32x16 hid[4];
-    zero_acc<4>(hid);
-    linear_acc<4, 4, T>(ws, 32, lane, nf, hid);
-    Frag<T> hf[8];
+        for (int nt = 0; nt < 2; ++nt) n[nt] += x[nt];
+        layernorm_acc<2>(n, ln, ln + 64, hh);
+        Frag<T> nf[4], xf[4];
+        acc_frags<2, T>(n, nf);
+        acc_frags<2, T>(x, xf);
+
+        f32x16 q[2], k[2], v[2], o[2];
+        zero_acc<2>(q); zero_acc<2>(k); zero_acc<2>(v); zero_acc<2>(o);
+        linear_lds<2, 4, T>(smem, 0, lane, nf, q);
+        linear_lds<2, 4, T>(smem, 8, lane, nf, k);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 2; ++nt)           // V[view, ch] = sum_k x[view, k] Wv[ch, k]: tokens are the A operand
 #pragma unroll
-        for (int i = 0; i < 16; ++i) hid[nt][i] = fmaxf(hid[nt][i], 0.0f);
-    acc_frags<4, T>(hid, hf);
-    linear_acc<2, 8, T>(ws, 48, lane, hf, x);
-    store_acc<2, T>(Y + off, ok, hh, x);
+            for (int ks = 0; ks < 4; ++ks) mma(xf[ks], frag_from_pieces(smem + (16 + nt * 4 + ks) * FB, lane, T()), v[nt]);
+
+#pragma unroll
+        for (int hd = 0; hd < 8; ++hd) {
+            const int nt = hd >> 2, s = (hd >> 1) & 1, half = hd & 1;
+            f32x16 S;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[i] = 0.0f;
+            mma(frag_half(acc_to_frag(k[nt], s, T()), half), acc_to_frag(q[nt], s, T()), S);   // S^T[kv, q]
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (acc_row(i, hh) >= V) S[i] = -INFINITY;
+                m = fmaxf(m, S[i]);
+            }
+            m = xhalf_max(m);
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { S[i] = exp2f(S[i] - m); sum += S[i]; }
+            const float inv = 1.0f / xhalf_sum(sum);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[i] *= inv;
+            const bool mine = (r >> 3) == (hd & 3);          // this lane's channel belongs to head hd
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                mma(frag_select<T>(mine, acc_to_frag(v[nt], s2, T())), acc_to_frag(S, s2, T()), o[nt]);
+        }
+
+        Frag<T> of[4];
+        acc_frags<2, T>(o, of);
+        linear_lds<2, 4, T>(smem, 24, lane, of, x);              // t = x + O Wo^T
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
+        layernorm_acc<2>(n, ln + 128, ln + 192, hh);
+        acc_frags<2, T>(n, nf);
+        f32x16 hid[4];
+        zero_acc<4>(hid);
+        linear_lds<4, 4, T>(smem, 32, lane, nf, hid);
+        Frag<T> hf[8];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hid[nt][i] = fmaxf(hid[nt][i], 0.0f);
+        acc_frags<4, T>(hid, hf);
+        linear_lds<2, 8, T>(smem, 48, lane, hf, x);
+        store_acc<2, T>(Y + off, ok, hh, x);
+    }
 }

@@ -12,20 +12,25 @@
 // Stream: conv[36 x 4] Wq[4x8] Wk[4x8] Wv[4x8]  (240 fragments).
 // PE_ONLY: embed the position image itself and write fp32 tokens (pack-time precompute).
 // ------------------------------------------------------------------------------------------
+constexpr int kSpaChunk = 16;   // fragments per ring chunk: one conv tap (4 k-steps x 4 row tiles), half an in_proj matrix
 template <typename T, bool PE_ONLY>
 __global__ __launch_bounds__(256) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const float* __restrict__ petok,
                                               T* __restrict__ TOK, T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vv,
                                               float* __restrict__ pe_out, int nimg, int h, int w) {
-    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const int hw = h * w, tpi = (hw + 31) >> 5;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= nimg * tpi) return;
-    const int im = tile / tpi, p = (tile % tpi) * 32 + r;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5, wave = threadIdx.x >> 6;
+    const int hw = h * w, tpi = (hw + 127) >> 7;
+    const int im = blockIdx.x / tpi, p0 = (blockIdx.x % tpi) * 128;
+    const int tl = wave * 32 + r, p = p0 + tl;
     const bool ok = p < hw;
+    char* lds_in = smem + WRing<T, kSpaChunk>::LDS_BYTES;
+    WRing<T, kSpaChunk> ring;
+    ring.init(ws, smem, PE_ONLY ? 144 : 240);
+    stage_conv_input<T>(X + (size_t)im * hw * 64, p0, hw, w, lds_in);
     f32x16 t[4];
     zero_acc<4>(t);
-    conv3x3_tile<4, T>(X + (size_t)im * hw * 64, p / w, p % w, ok, h, w, hh, ws, lane, t);
+    conv3x3_tile<4, T>(lds_in, tl, p / w, p % w, ok, h, w, hh, ring, t);
     if (PE_ONLY) {
         store_acc<4, float>(pe_out + (size_t)p * 128, ok, hh, t);
         return;
@@ -42,15 +47,15 @@ __global__ __launch_bounds__(256) void k_spa1(const T* __restrict__ X, const T* 
     {
         f32x16 a[4];
         zero_acc<4>(a);
-        linear_acc<4, 8, T>(ws, 144, lane, nf, a);
+        linear_ring<4, 8, T>(ring, nf, a);
         store_acc<4, T>(Q + off, ok, hh, a);
         zero_acc<4>(a);
-        linear_acc<4, 8, T>(ws, 176, lane, nf, a);
+        linear_ring<4, 8, T>(ring, nf, a);
         store_acc<4, T>(K + off, ok, hh, a);
     }
     acc_frags<4, T>(t, nf);
     zero_acc<4>(n);
-    linear_acc<4, 8, T>(ws, 208, lane, nf, n);
+    linear_ring<4, 8, T>(ring, nf, n);
     store_acc<4, T>(Vv + off, ok, hh, n);
 }
 
@@ -128,16 +133,18 @@ template <typename T, bool SKIP>
 __global__ __launch_bounds__(256) void k_spa2(const T* __restrict__ TOK, const T* __restrict__ O, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const T* __restrict__ skip, T* __restrict__ Y,
                                               long long ntok) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const long long tok = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + r;
-    if (tok - r >= ntok) return;
     const bool ok = tok < ntok;
+    WRing<T, kSpaChunk> ring;
+    ring.init(ws, smem, 176);
     f32x16 t[4], n[4];
     load_acc<4, T>(TOK + tok * 128, ok, hh, t);
     Frag<T> f[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) f[ks] = load_row8(O + tok * 128 + 16 * ks + 8 * hh, ok, T());
-    linear_acc<4, 8, T>(ws, 0, lane, f, t);
+    linear_ring<4, 8, T>(ring, f, t);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] = t[nt];
     layernorm_acc<4>(n, ln + 256, ln + 384, hh);
@@ -146,19 +153,19 @@ __global__ __launch_bounds__(256) void k_spa2(const T* __restrict__ TOK, const T
     for (int c = 0; c < 4; ++c) {
         f32x16 hid[2];
         zero_acc<2>(hid);
-        linear_acc<2, 8, T>(ws, 32 + 32 * c, lane, f, hid);
+        linear_ring<2, 8, T>(ring, f, hid);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) hid[nt][i] = fmaxf(hid[nt][i], 0.0f);
         Frag<T> hf[4];
         acc_frags<2, T>(hid, hf);
-        linear_acc<4, 4, T>(ws, 48 + 32 * c, lane, hf, t);
+        linear_ring<4, 4, T>(ring, hf, t);
     }
     acc_frags<4, T>(t, f);
     f32x16 y[2];
     zero_acc<2>(y);
-    linear_acc<2, 8, T>(ws, 160, lane, f, y);
+    linear_ring<2, 8, T>(ring, f, y);
     if (SKIP) {
         f32x16 sk[2];
         load_acc<2, T>(skip + tok * 64, ok, hh, sk);
@@ -179,10 +186,12 @@ __global__ __launch_bounds__(256) void k_spa2(const T* __restrict__ TOK, const T
 template <typename T, int GT>
 __global__ __launch_bounds__(256) void k_up(const T* __restrict__ X, const T* __restrict__ ws, float* __restrict__ G,
                                             long long ntok, int nchunk, int gp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const long long tok = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + r;
-    if (tok - r >= ntok) return;
     const bool ok = tok < ntok;
+    WRing<T, kSpaChunk> ring;
+    ring.init(ws, smem, nchunk * (4 + 2 * GT));
     f32x16 x[2];
     load_acc<2, T>(X + tok * 64, ok, hh, x);
     Frag<T> xf[4];
@@ -193,12 +202,12 @@ __global__ __launch_bounds__(256) void k_up(const T* __restrict__ X, const T* __
     for (int c = 0; c < nchunk; ++c) {
         f32x16 u[1];
         zero_acc<1>(u);
-        linear_acc<1, 4, T>(ws, c * (4 + 2 * GT), lane, xf, u);
+        linear_ring<1, 4, T>(ring, xf, u);
 #pragma unroll
         for (int i = 0; i < 16; ++i) u[0][i] = u[0][i] > 0.0f ? u[0][i] : 0.2f * u[0][i];
         Frag<T> uf[2];
         acc_frags<1, T>(u, uf);
-        linear_acc<GT, 2, T>(ws, c * (4 + 2 * GT) + 4, lane, uf, g);
+        linear_ring<GT, 2, T>(ring, uf, g);
     }
     if (!ok) return;
 #pragma unroll
