@@ -168,7 +168,11 @@ struct WRing {
     LFT_MEM Frag<T> next() {
         const int c = pos / CH, i = pos % CH;
         if (i == 0) {
-            __syncthreads();                                   // chunk c has landed (vmcnt(0) + barrier); chunk c-1 retired
+            // Every wave must see its own LDS-DMA pieces of chunk c landed BEFORE the barrier that publishes them.
+            // hipcc does not reliably insert this wait (k_up's loop had "s_waitcnt lgkmcnt(0); s_barrier" only, which
+            // raced under cold-start latency), so it is explicit.  It also waits for the wave's older ordinary loads.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                   // chunk c published; chunk c-1 retired (its buffer is re-filled next)
             if ((c + 1) * CH < nfrag) issue(c + 1);
         }
         ++pos;
@@ -177,15 +181,20 @@ struct WRing {
 };
 
 // 8 consecutive channels of a token row in memory -> fragment in NATURAL k order (k = 8h + j);
-// used where an operand comes straight from HBM (conv taps, attention output).
+// used where an operand comes straight from HBM (attention output).  Branch-free: the caller passes an
+// address that is always readable (clamped for out-of-range lanes) and the result is zeroed by `ok`, so the
+// compiler can issue all loads of a tile back to back instead of one exec-masked load + wait at a time.
 LFT_DEV Frag<float> load_row8(const float* __restrict__ p, bool ok, float) {
-    Frag<float> r = frag_zero(0.0f);
-    if (ok) { const f32x4* q = reinterpret_cast<const f32x4*>(p); r.lo = q[0]; r.hi = q[1]; }
+    Frag<float> r;
+    const f32x4* q = reinterpret_cast<const f32x4*>(p);
+    r.lo = q[0]; r.hi = q[1];
+    if (!ok) r = frag_zero(0.0f);
     return r;
 }
 LFT_DEV Frag<bf16_t> load_row8(const bf16_t* __restrict__ p, bool ok, bf16_t) {
-    Frag<bf16_t> r = frag_zero(bf16_t());
-    if (ok) r.v = *reinterpret_cast<const bf16x8*>(p);
+    Frag<bf16_t> r;
+    r.v = *reinterpret_cast<const bf16x8*>(p);
+    if (!ok) r = frag_zero(bf16_t());
     return r;
 }
 
@@ -221,16 +230,16 @@ LFT_DEV void store4(bf16_t* p, f32x4 v) {
     *reinterpret_cast<bf16x4*>(p) = o;
 }
 
+// `row` must be readable for every lane (clamp the token index); lanes with !ok get zeros.
 template <int NT, typename T>
 LFT_DEV void load_acc(const T* __restrict__ row, bool ok, int h, f32x16 (&a)[NT]) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 v = f32x4{0, 0, 0, 0};
-            if (ok) v = load4(row + 32 * nt + 8 * g + 4 * h);
+            const f32x4 v = load4(row + 32 * nt + 8 * g + 4 * h);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[nt][4 * g + j] = v[j];
+            for (int j = 0; j < 4; ++j) a[nt][4 * g + j] = ok ? v[j] : 0.0f;
         }
     }
 }

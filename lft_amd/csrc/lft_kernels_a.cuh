@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void k_conv64(const T* __restrict__ in, T* __r
     const int im = blockIdx.x / tpi, p0 = (blockIdx.x % tpi) * 128;
     const int tl = wave * 32 + r, p = p0 + tl;
     const bool ok = p < hw;
+    const size_t off = ((size_t)im * hw + min(p, hw - 1)) * 64;
+    f32x16 rr[2];
+    if (RES) load_acc<2, T>(res + off, ok, hh, rr);           // issued first: its latency hides under the whole tile
     char* lds_in = smem + WRing<T, kConv64Chunk>::LDS_BYTES;
     WRing<T, kConv64Chunk> ring;
     ring.init(wstream, smem, 72);
@@ -180,10 +183,7 @@ __global__ __launch_bounds__(256) void k_conv64(const T* __restrict__ in, T* __r
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = acc[nt][i] > 0.0f ? acc[nt][i] : 0.2f * acc[nt][i];
-    const size_t off = ((size_t)im * hw + p) * 64;
     if (RES) {
-        f32x16 rr[2];
-        load_acc<2, T>(res + off, ok, hh, rr);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[nt] += rr[nt];
     }
@@ -214,7 +214,7 @@ LFT_DEV void linear_lds(const char* wl, int f0, int lane, const Frag<T> (&x)[KS]
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_ang(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ ws,
+__global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ ws,
                                              const float* __restrict__ ln, const float* __restrict__ pe,
                                              int V, int hw, int npix) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -229,16 +229,17 @@ __global__ __launch_bounds__(256) void k_ang(const T* __restrict__ X, T* __restr
             glds_piece(g + piece * 1024, smem + piece * 1024, lane);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own LDS-DMA pieces landed, then publish (see WRing::next)
     __syncthreads();
     const bool ok = r < V;
     for (int pix = blockIdx.x * 4 + wave; pix < npix; pix += gridDim.x * 4) {
         asm volatile("" ::: "memory");    // keep the (loop-invariant) LDS weight reads inside the loop: hoisted, they cost 256+ VGPRs
-        const int b = pix / hw, p = pix % hw;
-        const size_t off = (((size_t)b * V + r) * hw + p) * 64;
+        const int b = pix / hw, p = pix % hw, rc = min(r, V - 1);
+        const size_t off = (((size_t)b * V + rc) * hw + p) * 64;
 
         f32x16 x[2], n[2];
         load_acc<2, T>(X + off, ok, hh, x);
-        load_acc<2, float>(pe + (size_t)r * 64, ok, hh, n);
+        load_acc<2, float>(pe + (size_t)rc * 64, ok, hh, n);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) n[nt] += x[nt];
         layernorm_acc<2>(n, ln, ln + 64, hh);

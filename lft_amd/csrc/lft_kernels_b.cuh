@@ -14,7 +14,7 @@
 // ------------------------------------------------------------------------------------------
 constexpr int kSpaChunk = 16;   // fragments per ring chunk: one conv tap (4 k-steps x 4 row tiles), half an in_proj matrix
 template <typename T, bool PE_ONLY>
-__global__ __launch_bounds__(256) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
+__global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const float* __restrict__ petok,
                                               T* __restrict__ TOK, T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vv,
                                               float* __restrict__ pe_out, int nimg, int h, int w) {
@@ -24,6 +24,9 @@ __global__ __launch_bounds__(256) void k_spa1(const T* __restrict__ X, const T* 
     const int im = blockIdx.x / tpi, p0 = (blockIdx.x % tpi) * 128;
     const int tl = wave * 32 + r, p = p0 + tl;
     const bool ok = p < hw;
+    const int pc = min(p, hw - 1);
+    f32x16 n[4];
+    if (!PE_ONLY) load_acc<4, float>(petok + (size_t)pc * 128, ok, hh, n);   // early: latency hides under the conv
     char* lds_in = smem + WRing<T, kSpaChunk>::LDS_BYTES;
     WRing<T, kSpaChunk> ring;
     ring.init(ws, smem, PE_ONLY ? 144 : 240);
@@ -32,13 +35,11 @@ __global__ __launch_bounds__(256) void k_spa1(const T* __restrict__ X, const T* 
     zero_acc<4>(t);
     conv3x3_tile<4, T>(lds_in, tl, p / w, p % w, ok, h, w, hh, ring, t);
     if (PE_ONLY) {
-        store_acc<4, float>(pe_out + (size_t)p * 128, ok, hh, t);
+        store_acc<4, float>(pe_out + (size_t)pc * 128, ok, hh, t);
         return;
     }
-    const size_t off = ((size_t)im * hw + p) * 128;
+    const size_t off = ((size_t)im * hw + pc) * 128;
     store_acc<4, T>(TOK + off, ok, hh, t);
-    f32x16 n[4];
-    load_acc<4, float>(petok + (size_t)p * 128, ok, hh, n);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] += t[nt];
     layernorm_acc<4>(n, ln, ln + 128, hh);
@@ -130,20 +131,23 @@ __global__ __launch_bounds__(256) void k_spa_attn(const T* __restrict__ Q, const
 // Stream: Wo[4x8, natural k] {W1c[2x8] W2c[4x4]} x4  Wl[2x8]  (176 fragments).
 // ------------------------------------------------------------------------------------------
 template <typename T, bool SKIP>
-__global__ __launch_bounds__(256) void k_spa2(const T* __restrict__ TOK, const T* __restrict__ O, const T* __restrict__ ws,
+__global__ __launch_bounds__(256, 2) void k_spa2(const T* __restrict__ TOK, const T* __restrict__ O, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const T* __restrict__ skip, T* __restrict__ Y,
                                               long long ntok) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const long long tok = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + r;
-    const bool ok = tok < ntok;
-    WRing<T, kSpaChunk> ring;
-    ring.init(ws, smem, 176);
+    const long long tok_raw = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + r;
+    const bool ok = tok_raw < ntok;
+    const long long tok = ok ? tok_raw : ntok - 1;
     f32x16 t[4], n[4];
     load_acc<4, T>(TOK + tok * 128, ok, hh, t);
     Frag<T> f[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) f[ks] = load_row8(O + tok * 128 + 16 * ks + 8 * hh, ok, T());
+    f32x16 sk[2];
+    if (SKIP) load_acc<2, T>(skip + tok * 64, ok, hh, sk);
+    WRing<T, kSpaChunk> ring;
+    ring.init(ws, smem, 176);
     linear_ring<4, 8, T>(ring, f, t);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] = t[nt];
@@ -167,8 +171,6 @@ __global__ __launch_bounds__(256) void k_spa2(const T* __restrict__ TOK, const T
     zero_acc<2>(y);
     linear_ring<2, 8, T>(ring, f, y);
     if (SKIP) {
-        f32x16 sk[2];
-        load_acc<2, T>(skip + tok * 64, ok, hh, sk);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) y[nt] += sk[nt];
     }
@@ -188,12 +190,13 @@ __global__ __launch_bounds__(256) void k_up(const T* __restrict__ X, const T* __
                                             long long ntok, int nchunk, int gp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const long long tok = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + r;
-    const bool ok = tok < ntok;
-    WRing<T, kSpaChunk> ring;
-    ring.init(ws, smem, nchunk * (4 + 2 * GT));
+    const long long tok_raw = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + r;
+    const bool ok = tok_raw < ntok;
+    const long long tok = ok ? tok_raw : ntok - 1;
     f32x16 x[2];
     load_acc<2, T>(X + tok * 64, ok, hh, x);
+    WRing<T, kSpaChunk> ring;
+    ring.init(ws, smem, nchunk * (4 + 2 * GT));
     Frag<T> xf[4];
     acc_frags<2, T>(x, xf);
     f32x16 g[GT];
