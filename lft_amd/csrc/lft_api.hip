@@ -119,9 +119,10 @@ WorkLayout work_layout(const Dims& d, int prec) {
 
 // Dynamic LDS sizes (bytes) and the opt-in above the 64 KiB default (a workgroup may use all 160 KiB of a CU).
 template <typename T> size_t lds_conv64(int w) { return WRing<T, kConv64Chunk>::LDS_BYTES + ConvIn<T>::bytes(w); }
-template <typename T> size_t lds_spa1(int w) { return WRing<T, kSpaChunk>::LDS_BYTES + ConvIn<T>::bytes(w); }
-template <typename T> size_t lds_ring() { return WRing<T, kSpaChunk>::LDS_BYTES; }
-template <typename T> size_t lds_ang() { return (size_t)kFragsAng * 1024 * FragInfo<T>::PIECES; }
+constexpr size_t kLdsParams = 1024;   // 256 LayerNorm floats
+template <typename T> size_t lds_spa1(int w) { return WRing<T, kSpaChunk>::LDS_BYTES + ConvIn<T>::bytes(w) + kLdsParams; }
+template <typename T> size_t lds_ring() { return WRing<T, kSpaChunk>::LDS_BYTES + kLdsParams; }
+template <typename T> size_t lds_ang() { return (size_t)kFragsAng * 1024 * FragInfo<T>::PIECES + kLdsParams; }
 constexpr size_t kMaxLds = 160 * 1024;
 template <typename K> int allow_lds(K kernel, size_t bytes, const char* name) {
     if (bytes > kMaxLds) return fail(LFT_ERR_SHAPE, "%s needs %zu B of LDS (> 160 KiB): view width too large for this build", name, bytes);
@@ -280,7 +281,12 @@ int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, con
     k_spa1<T, false><<<nwg, 256, lds_spa1<T>(d.w), st>>>(in, at<T>(packed, L.s_spa1[l]), ln, at<float>(packed, L.petok[l]),
                                                          tok, q, k, v, nullptr, nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_spa1");
-    k_spa_attn<T><<<blocks_for(d.ntok * 8, 256), 256, 0, st>>>(q, k, v, o, d.ntok, d.h, d.w);
+    if constexpr (sizeof(T) == 2) {
+        const dim3 grid((unsigned)(nimg * ((d.h + kAttTY - 1) / kAttTY) * ((d.w + kAttTX - 1) / kAttTX)), 2);
+        k_spa_attn_lds<<<grid, 512, kAttLds, st>>>(q, k, v, o, d.h, d.w);
+    } else {
+        k_spa_attn<T><<<blocks_for(d.ntok * 8, 256), 256, 0, st>>>(q, k, v, o, d.ntok, d.h, d.w);
+    }
     LFT_LAUNCH_OK("k_spa_attn");
     const unsigned nb = blocks_for(d.ntok, 128);
     if ((rc = allow_lds(k_spa2<T, true>, lds_ring<T>(), "k_spa2"))) return rc;
@@ -481,6 +487,20 @@ int lft_debug_conv64(const void* packed, int which, int with_res, const void* in
     LFT_LAUNCH_OK("k_conv64");
     return 0;
 }
+
+#ifdef LFT_STAMPS
+// Diagnostic build only: copy the stamp buffer to the host (synchronises).
+int lft_debug_read_stamps(unsigned long long* host_out, int n) {
+    LFT_HIP_OK(hipDeviceSynchronize());
+    LFT_HIP_OK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_lft_stamps), sizeof(unsigned long long) * (size_t)n));
+    return 0;
+}
+int lft_debug_clear_stamps(void) {
+    static unsigned long long zeros[4096 * 16];
+    LFT_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_lft_stamps), zeros, sizeof(zeros)));
+    return 0;
+}
+#endif
 
 int lft_mfma_selftest(const float* Am, const float* Bm, const float* W2, float* C, float* D, int prec, void* stream) {
     if (!Am || !Bm || !W2 || !C || !D) return fail(LFT_ERR_ARG, "null pointer");

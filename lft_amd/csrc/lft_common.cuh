@@ -31,6 +31,22 @@ typedef unsigned int raw16 __attribute__((ext_vector_type(4), may_alias));
 #define LFT_DEV static __device__ __forceinline__
 #define LFT_MEM __device__ __forceinline__
 
+// Diagnostic build only (-DLFT_STAMPS): per-phase s_memtime stamps of wave 0 of every workgroup go to a
+// side buffer that no kernel reads (tools/stamp_report.py).  In the product build LFT_STAMP() is empty.
+#ifdef LFT_STAMPS
+__device__ unsigned long long g_lft_stamps[4096 * 16];
+LFT_DEV void lft_stamp(int slot) {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_lft_stamps[blockIdx.x * 16 + slot] = t;
+}
+#define LFT_STAMP(slot) lft_stamp(slot)
+#else
+#define LFT_STAMP(slot) ((void)0)
+#endif
+
 constexpr int LFT_C = 64;            // feature channels (reference option.py --channels, LFT.py:11)
 constexpr int LFT_E = 128;           // spatial token width 2C (reference LFT.py:124)
 constexpr float LFT_LN_EPS = 1e-5f;  // nn.LayerNorm default
@@ -135,17 +151,26 @@ LFT_DEV void glds_piece(const char* __restrict__ gsrc, char* lds_dst, int lane) 
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// Weight ring: the 4 waves of a workgroup consume the same fragment stream in lock-step.  The stream is
-// cut into chunks of CH fragments; chunk c+1 is DMA'd into the other half of a 2-slot LDS ring while
-// chunk c feeds the MFMAs.  next() must be called by all 256 threads at the same program points (it
-// contains the workgroup barrier that publishes a chunk and retires the previous one).
+// Weight ring: the 4 waves of a workgroup consume the same fragment stream in lock-step.  The stream is cut
+// into chunks of CH fragments held in a 3-slot LDS ring: while chunk c feeds the MFMAs, chunks c+1 and c+2 are
+// in flight / landed (LDS-DMA issued two chunks ahead: one chunk of MFMAs, ~0.25 us, is shorter than the
+// L2 -> LDS latency, so a 2-slot ring stalled at every chunk boundary).  next() must be called by all 256
+// threads at the same program points: at the first fragment of a chunk it
+//   1. waits until this wave's own DMA pieces of chunk c have landed -- a COUNTED vmcnt that leaves the
+//      pieces of chunk c+1 (the youngest VM operations) in flight.  vmcnt retires in issue order, so any
+//      younger ordinary load/store only makes the wait stricter, never unsafe.  hipcc does NOT insert this
+//      wait reliably for LDS-DMA (k_up's loop had a bare "s_waitcnt lgkmcnt(0); s_barrier"), so it is explicit;
+//   2. executes the workgroup barrier: chunk c is published, chunk c-1 is retired by every wave;
+//   3. issues the DMA of chunk c+2 into the slot chunk c-1 just vacated.
 template <typename T, int CH>
 struct WRing {
+    static constexpr int NBUF = 3;
     static constexpr int FRAG_BYTES = 1024 * FragInfo<T>::PIECES;
     static constexpr int CHUNK_BYTES = CH * FRAG_BYTES;
-    static constexpr int LDS_BYTES = 2 * CHUNK_BYTES;
+    static constexpr int LDS_BYTES = NBUF * CHUNK_BYTES;
     static constexpr int PIECES_PER_WAVE = CH * FragInfo<T>::PIECES / 4;
     static_assert((CH * FragInfo<T>::PIECES) % 4 == 0, "chunk must split over 4 waves");
+    static_assert(PIECES_PER_WAVE <= 12, "counted vmcnt immediates below cover up to 12 pieces per wave");
     const char* g;
     char* lds;
     int lane, wave, pos, nfrag;
@@ -154,31 +179,46 @@ struct WRing {
         lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         issue(0);
+        issue(1);
     }
+    // Every wave issues exactly PIECES_PER_WAVE DMA instructions per chunk (clamped to the last piece of the
+    // stream when the chunk is short) so that the counted wait below is exact.
     LFT_MEM void issue(int c) {
+        if (c * CH >= nfrag) return;                                   // uniform: chunk does not exist
         const char* src = g + (size_t)c * CHUNK_BYTES;
-        char* dst = lds + (c & 1) * CHUNK_BYTES;
-        const int left = (nfrag - c * CH) * FragInfo<T>::PIECES;       // pieces that exist in this chunk
+        char* dst = lds + (c % NBUF) * CHUNK_BYTES;
+        const int last = (nfrag - c * CH) * FragInfo<T>::PIECES - 1;    // last piece that exists in this chunk
 #pragma unroll
         for (int i = 0; i < PIECES_PER_WAVE; ++i) {
-            const int piece = wave * PIECES_PER_WAVE + i;
-            if (piece < left) glds_piece(src + piece * 1024, dst + piece * 1024, lane);
+            const int piece = min(wave * PIECES_PER_WAVE + i, last);
+            glds_piece(src + piece * 1024, dst + piece * 1024, lane);
+        }
+    }
+    LFT_MEM void wait_landed(bool next_in_flight) {
+        if (next_in_flight) {
+            if constexpr (PIECES_PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if constexpr (PIECES_PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if constexpr (PIECES_PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (PIECES_PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (PIECES_PER_WAVE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (PIECES_PER_WAVE == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
     LFT_MEM Frag<T> next() {
         const int c = pos / CH, i = pos % CH;
         if (i == 0) {
-            // Every wave must see its own LDS-DMA pieces of chunk c landed BEFORE the barrier that publishes them.
-            // hipcc does not reliably insert this wait (k_up's loop had "s_waitcnt lgkmcnt(0); s_barrier" only, which
-            // raced under cold-start latency), so it is explicit.  It also waits for the wave's older ordinary loads.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                   // chunk c published; chunk c-1 retired (its buffer is re-filled next)
-            if ((c + 1) * CH < nfrag) issue(c + 1);
+            wait_landed((c + 1) * CH < nfrag);
+            __syncthreads();
+            issue(c + 2);
         }
         ++pos;
-        return frag_from_pieces(lds + (c & 1) * CHUNK_BYTES + i * FRAG_BYTES, lane, T());
+        return frag_from_pieces(lds + (c % NBUF) * CHUNK_BYTES + i * FRAG_BYTES, lane, T());
     }
 };
+
 
 // 8 consecutive channels of a token row in memory -> fragment in NATURAL k order (k = 8h + j);
 // used where an operand comes straight from HBM (attention output).  Branch-free: the caller passes an
@@ -267,9 +307,11 @@ LFT_DEV float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 LFT_DEV float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
 
 // LayerNorm over the NT*32 channels of each token (biased variance, eps inside the sqrt, affine),
-// as nn.LayerNorm does (reference LFT.py:127,136,199,208).  In place.
+// as nn.LayerNorm does (reference LFT.py:127,136,199,208).  In place.  gamma/beta may point to LDS (kernels
+// copy the small parameter vectors there at start: a global load in the middle of a kernel would force a
+// vmcnt(0) that also drains the weight ring's in-flight LDS-DMA).
 template <int NT>
-LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* __restrict__ gamma, const float* __restrict__ beta, int h) {
+LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* gamma, const float* beta, int h) {
     float s = 0.0f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -286,11 +328,17 @@ LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* __restrict__ gamma, con
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 gm = load4(gamma + 32 * nt + 8 * g + 4 * h);
-            const f32x4 bt = load4(beta + 32 * nt + 8 * g + 4 * h);
+            const f32x4 gm = __builtin_bit_cast(f32x4, load_raw16(reinterpret_cast<const char*>(gamma + 32 * nt + 8 * g + 4 * h)));
+            const f32x4 bt = __builtin_bit_cast(f32x4, load_raw16(reinterpret_cast<const char*>(beta + 32 * nt + 8 * g + 4 * h)));
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[nt][4 * g + j] = (a[nt][4 * g + j] - mean) * rstd * gm[j] + bt[j];
         }
+}
+// copy n floats (n % 4 == 0, n <= 1024) of LayerNorm parameters global -> LDS; caller synchronises (the first
+// ring barrier, or an explicit one, comes before any use).
+LFT_DEV void stage_params(const float* __restrict__ src, float* lds_dst, int n) {
+    const int i = threadIdx.x * 4;
+    if (i < n) store_raw16(reinterpret_cast<char*>(lds_dst + i), load_raw16(reinterpret_cast<const char*>(src + i)));
 }
 
 // all 2*NT k-steps of an accumulator-resident activation as fragments

@@ -129,12 +129,23 @@ template <typename T> struct ConvIn {
 template <typename T>
 LFT_DEV void stage_conv_input(const T* __restrict__ img, int p0, int hw, int w, char* lds_in) {
     const int n = ConvIn<T>::slots(w) * ConvIn<T>::PPR;
-    for (int idx = threadIdx.x; idx < n; idx += 256) {
-        const int slot = idx / ConvIn<T>::PPR, piece = idx % ConvIn<T>::PPR;
-        const int q = p0 - w - 1 + slot;
-        raw16 v = raw16{0u, 0u, 0u, 0u};
-        if (q >= 0 && q < hw) v = load_raw16(reinterpret_cast<const char*>(img) + ((size_t)q * 64 * sizeof(T) + piece * 16));
-        store_raw16(lds_in + slot * ConvIn<T>::ROW_BYTES + piece * 16, v);
+    constexpr int BATCH = 4;                  // loads in flight per thread: issue all, then store all (no per-pass round trip)
+    for (int base = threadIdx.x; base < n; base += 256 * BATCH) {
+        raw16 v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = min(base + 256 * u, n - 1);
+            const int slot = idx / ConvIn<T>::PPR, piece = idx % ConvIn<T>::PPR;
+            const int q = p0 - w - 1 + slot;
+            const bool in = q >= 0 && q < hw;
+            const raw16 t = load_raw16(reinterpret_cast<const char*>(img) + ((size_t)(in ? q : 0) * 64 * sizeof(T) + piece * 16));
+            v[u] = in ? t : raw16{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = base + 256 * u;
+            if (idx < n) store_raw16(lds_in + (idx / ConvIn<T>::PPR) * ConvIn<T>::ROW_BYTES + (idx % ConvIn<T>::PPR) * 16, v[u]);
+        }
     }
     __syncthreads();   // publish the tile: conv3x3_tile reads a B fragment BEFORE its first ring.next() barrier
 }
@@ -159,7 +170,7 @@ LFT_DEV void conv3x3_tile(const char* lds_in, int tl, int y, int x, bool ok, int
 }
 
 // conv_init[i]: 64 -> 64 + LeakyReLU(0.2); the last one adds conv_init0's output (reference LFT.py:26-33,66).
-constexpr int kConv64Chunk = 24;   // 72 fragments = 3 chunks of 3 taps
+constexpr int kConv64Chunk = 12;   // 72 fragments = 6 chunks; 3-slot ring = 36 KiB (bf16) so two workgroups share a CU
 template <typename T, bool RES>
 __global__ __launch_bounds__(256) void k_conv64(const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ res,
                                                 const T* __restrict__ wstream, int nimg, int h, int w) {
@@ -229,6 +240,8 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
             glds_piece(g + piece * 1024, smem + piece * 1024, lane);
         }
     }
+    float* lds_ln = reinterpret_cast<float*>(smem + 64 * FB);
+    stage_params(ln, lds_ln, 256);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own LDS-DMA pieces landed, then publish (see WRing::next)
     __syncthreads();
     const bool ok = r < V;
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
         load_acc<2, float>(pe + (size_t)rc * 64, ok, hh, n);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) n[nt] += x[nt];
-        layernorm_acc<2>(n, ln, ln + 64, hh);
+        layernorm_acc<2>(n, lds_ln, lds_ln + 64, hh);
         Frag<T> nf[4], xf[4];
         acc_frags<2, T>(n, nf);
         acc_frags<2, T>(x, xf);
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
         linear_lds<2, 4, T>(smem, 24, lane, of, x);              // t = x + O Wo^T
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
-        layernorm_acc<2>(n, ln + 128, ln + 192, hh);
+        layernorm_acc<2>(n, lds_ln + 128, lds_ln + 192, hh);
         acc_frags<2, T>(n, nf);
         f32x16 hid[4];
         zero_acc<4>(hid);

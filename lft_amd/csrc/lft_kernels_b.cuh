@@ -25,15 +25,20 @@ __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const 
     const int tl = wave * 32 + r, p = p0 + tl;
     const bool ok = p < hw;
     const int pc = min(p, hw - 1);
+    LFT_STAMP(0);
     f32x16 n[4];
     if (!PE_ONLY) load_acc<4, float>(petok + (size_t)pc * 128, ok, hh, n);   // early: latency hides under the conv
     char* lds_in = smem + WRing<T, kSpaChunk>::LDS_BYTES;
+    float* lds_ln = reinterpret_cast<float*>(lds_in + ConvIn<T>::bytes(w));
+    if (!PE_ONLY) stage_params(ln, lds_ln, 256);                      // norm.{weight,bias}; published by the staging barrier
     WRing<T, kSpaChunk> ring;
     ring.init(ws, smem, PE_ONLY ? 144 : 240);
     stage_conv_input<T>(X + (size_t)im * hw * 64, p0, hw, w, lds_in);
+    LFT_STAMP(1);
     f32x16 t[4];
     zero_acc<4>(t);
     conv3x3_tile<4, T>(lds_in, tl, p / w, p % w, ok, h, w, hh, ring, t);
+    LFT_STAMP(2);
     if (PE_ONLY) {
         store_acc<4, float>(pe_out + (size_t)pc * 128, ok, hh, t);
         return;
@@ -42,9 +47,10 @@ __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const 
     store_acc<4, T>(TOK + off, ok, hh, t);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] += t[nt];
-    layernorm_acc<4>(n, ln, ln + 128, hh);
+    layernorm_acc<4>(n, lds_ln, lds_ln + 128, hh);
     Frag<T> nf[8];
     acc_frags<4, T>(n, nf);
+    LFT_STAMP(3);
     {
         f32x16 a[4];
         zero_acc<4>(a);
@@ -54,10 +60,13 @@ __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const 
         linear_ring<4, 8, T>(ring, nf, a);
         store_acc<4, T>(K + off, ok, hh, a);
     }
+    LFT_STAMP(4);
     acc_frags<4, T>(t, nf);
     zero_acc<4>(n);
     linear_ring<4, 8, T>(ring, nf, n);
+    LFT_STAMP(5);
     store_acc<4, T>(Vv + off, ok, hh, n);
+    LFT_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -124,6 +133,158 @@ __global__ __launch_bounds__(256) void k_spa_attn(const T* __restrict__ Q, const
         store4(O + tok * 128 + head * 16 + 4 * g, f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv});
 }
 
+// bf16 specialisation: the head's 16 channels stay packed (8 x bf16 pairs); Q.K uses v_dot2c_f32_bf16 on the raw
+// pairs (no unpacking), and P.V accumulates with the same instruction against (p, 0) / (0, p) so V is never
+// unpacked either: ~700 VALU instructions per (query, head) instead of ~2500.  P is rounded to bf16 as an MFMA
+// operand would be; all accumulation is fp32.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+LFT_DEV void load_pairs16(const bf16_t* p, bf16x2 (&o)[8]) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p), b = *reinterpret_cast<const bf16x8*>(p + 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = bf16x2{a[2 * i], a[2 * i + 1]}; o[4 + i] = bf16x2{b[2 * i], b[2 * i + 1]}; }
+}
+template <>
+__global__ __launch_bounds__(256) void k_spa_attn<bf16_t>(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                          const bf16_t* __restrict__ Vv, bf16_t* __restrict__ O, long long ntok,
+                                                          int h, int w) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long tok = idx >> 3;
+    const int head = (int)(idx & 7);
+    if (tok >= ntok) return;
+    const int hw = h * w;
+    const int p = (int)(tok % hw);
+    const long long img0 = tok - p;
+    const int y = p / w, x = p % w;
+    const int y0 = max(0, y - 2), y1 = min(h, y + 3), x0 = max(0, x - 2), x1 = min(min(h, x + 3), w);
+    bf16x2 q[8], kv[8];
+    float s[25];
+    load_pairs16(Q + tok * 128 + head * 16, q);
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
+        s[t] = -INFINITY;
+        if (ky >= y0 && ky < y1 && kx >= x0 && kx < x1) {
+            load_pairs16(K + (img0 + ky * w + kx) * 128 + head * 16, kv);
+            float d = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) d = __builtin_amdgcn_fdot2_f32_bf16(q[c], kv[c], d, false);
+            s[t] = d;
+        }
+        m = fmaxf(m, s[t]);
+    }
+    float sum = 0.0f, o[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) o[c] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
+        if (s[t] != -INFINITY) {
+            const float pr = exp2f(s[t] - m);
+            sum += pr;
+            const bf16_t pb = (bf16_t)pr;
+            const bf16x2 p0 = bf16x2{pb, (bf16_t)0.0f}, p1 = bf16x2{(bf16_t)0.0f, pb};
+            load_pairs16(Vv + (img0 + ky * w + kx) * 128 + head * 16, kv);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                o[2 * c] = __builtin_amdgcn_fdot2_f32_bf16(p0, kv[c], o[2 * c], false);
+                o[2 * c + 1] = __builtin_amdgcn_fdot2_f32_bf16(p1, kv[c], o[2 * c + 1], false);
+            }
+        }
+    }
+    const float inv = 1.0f / sum;      // empty window -> NaN, see the generic kernel
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        store4(O + tok * 128 + head * 16 + 4 * g, f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv});
+}
+
+// LDS-tiled bf16 windowed attention (the production path; the per-thread kernels above remain for fp32).
+// A 512-thread workgroup owns a 4 x 32 tile of queries of one view image and 4 of the 8 heads (64 channels).
+// The (4+4) x (32+4) halo tile of K -- then of V, re-using the same 41 KiB -- is staged once into LDS (every key is
+// used by up to 25 queries x 4 heads), token rows padded to 144 B so the 16-byte reads of a half-wave (32 different
+// query columns) fall on distinct banks.  wave = (head, 2 query rows), lane = (row parity, column).
+constexpr int kAttTY = 4, kAttTX = 32, kAttHR = kAttTY + 4, kAttHC = kAttTX + 4, kAttRow = 144;
+constexpr int kAttLds = kAttHR * kAttHC * kAttRow;
+LFT_DEV void att_stage(const bf16_t* __restrict__ src, char* lds, long long img_tok0, int ty, int tx, int hg, int h, int w) {
+    constexpr int N = kAttHR * kAttHC * 8, ITER = (N + 511) / 512;       // 2304 16-byte pieces, 5 per thread
+    raw16 v[ITER];
+#pragma unroll
+    for (int u = 0; u < ITER; ++u) {                                       // all loads first (branch-free), then all stores
+        const int idx = min((int)threadIdx.x + 512 * u, N - 1);
+        const int slot = idx >> 3, piece = idx & 7;
+        const int gy = ty * kAttTY - 2 + slot / kAttHC, gx = tx * kAttTX - 2 + slot % kAttHC;
+        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+        const long long t = in ? img_tok0 + gy * w + gx : img_tok0;
+        const raw16 r = load_raw16(reinterpret_cast<const char*>(src + t * 128 + hg * 64) + piece * 16);
+        v[u] = in ? r : raw16{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int u = 0; u < ITER; ++u) {
+        const int idx = (int)threadIdx.x + 512 * u;
+        if (idx < N) store_raw16(lds + (idx >> 3) * kAttRow + (idx & 7) * 16, v[u]);
+    }
+}
+LFT_DEV void lds_pairs16(const char* p, bf16x2 (&o)[8]) {
+    const bf16x8 a = __builtin_bit_cast(bf16x8, load_raw16(p)), b = __builtin_bit_cast(bf16x8, load_raw16(p + 16));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = bf16x2{a[2 * i], a[2 * i + 1]}; o[4 + i] = bf16x2{b[2 * i], b[2 * i + 1]}; }
+}
+__global__ __launch_bounds__(512) void k_spa_attn_lds(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                      const bf16_t* __restrict__ Vv, bf16_t* __restrict__ O, int h, int w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_x = (w + kAttTX - 1) / kAttTX, tiles_y = (h + kAttTY - 1) / kAttTY;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, im = blockIdx.x / (tiles_x * tiles_y);
+    const int hg = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hl = wave & 3, qrow = (wave >> 2) * 2 + (lane >> 5), qcol = lane & 31;
+    const int y = ty * kAttTY + qrow, x = tx * kAttTX + qcol;
+    const bool valid = y < h && x < w;
+    const long long img0 = (long long)im * h * w;
+    const long long tok = img0 + min(y, h - 1) * w + min(x, w - 1);
+    const int y0 = max(0, y - 2), y1 = min(h, y + 3), x0 = max(0, x - 2), x1 = min(min(h, x + 3), w);   // reference LFT.py:155 (sic)
+    bf16x2 q[8], kv[8];
+    load_pairs16(Q + tok * 128 + hg * 64 + hl * 16, q);
+    att_stage(K, smem, img0, ty, tx, hg, h, w);
+    __syncthreads();
+    float s[25];
+    float m = -INFINITY;
+    const char* base = smem + (qrow * kAttHC + qcol) * kAttRow + hl * 32;
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
+        lds_pairs16(base + ((t / 5) * kAttHC + t % 5) * kAttRow, kv);
+        float d = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) d = __builtin_amdgcn_fdot2_f32_bf16(q[c], kv[c], d, false);
+        s[t] = (ky >= y0 && ky < y1 && kx >= x0 && kx < x1) ? d : -INFINITY;
+        m = fmaxf(m, s[t]);
+    }
+    __syncthreads();                       // everyone is done with K
+    att_stage(Vv, smem, img0, ty, tx, hg, h, w);
+    __syncthreads();
+    float sum = 0.0f, o[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) o[c] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        const float pr = (s[t] != -INFINITY) ? exp2f(s[t] - m) : 0.0f;
+        sum += pr;
+        const bf16_t pb = (bf16_t)pr;
+        const bf16x2 p0 = bf16x2{pb, (bf16_t)0.0f}, p1 = bf16x2{(bf16_t)0.0f, pb};
+        lds_pairs16(base + ((t / 5) * kAttHC + t % 5) * kAttRow, kv);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            o[2 * c] = __builtin_amdgcn_fdot2_f32_bf16(p0, kv[c], o[2 * c], false);
+            o[2 * c + 1] = __builtin_amdgcn_fdot2_f32_bf16(p1, kv[c], o[2 * c + 1], false);
+        }
+    }
+    if (!valid) return;
+    const float inv = 1.0f / sum;          // empty window (h < w quirk): 0 * inf = NaN as in the reference
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        store4(O + tok * 128 + hg * 64 + hl * 16 + 4 * g, f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv});
+}
+
 // ------------------------------------------------------------------------------------------
 // SpaTrans part 2 (reference LFT.py:187-189, 171-174): per 32-token tile
 //   t  = tok + O Wo^T ;  t2 = t + W2 relu(W1 LN'(t)) ;  y = Wl t2  (Conv3d 1x1x1 128->64)  [+ global skip, LFT.py:76]
@@ -139,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void k_spa2(const T* __restrict__ TOK, cons
     const long long tok_raw = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + r;
     const bool ok = tok_raw < ntok;
     const long long tok = ok ? tok_raw : ntok - 1;
+    LFT_STAMP(0);
     f32x16 t[4], n[4];
     load_acc<4, T>(TOK + tok * 128, ok, hh, t);
     Frag<T> f[8];
@@ -146,13 +308,18 @@ __global__ __launch_bounds__(256, 2) void k_spa2(const T* __restrict__ TOK, cons
     for (int ks = 0; ks < 8; ++ks) f[ks] = load_row8(O + tok * 128 + 16 * ks + 8 * hh, ok, T());
     f32x16 sk[2];
     if (SKIP) load_acc<2, T>(skip + tok * 64, ok, hh, sk);
+    float* lds_ln = reinterpret_cast<float*>(smem + WRing<T, kSpaChunk>::LDS_BYTES);
+    stage_params(ln + 256, lds_ln, 256);                              // feed_forward.0.{weight,bias}; published by the first ring barrier
     WRing<T, kSpaChunk> ring;
     ring.init(ws, smem, 176);
+    LFT_STAMP(1);
     linear_ring<4, 8, T>(ring, f, t);
+    LFT_STAMP(2);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] = t[nt];
-    layernorm_acc<4>(n, ln + 256, ln + 384, hh);
+    layernorm_acc<4>(n, lds_ln, lds_ln + 128, hh);
     acc_frags<4, T>(n, f);
+    LFT_STAMP(3);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         f32x16 hid[2];
@@ -166,15 +333,18 @@ __global__ __launch_bounds__(256, 2) void k_spa2(const T* __restrict__ TOK, cons
         acc_frags<2, T>(hid, hf);
         linear_ring<4, 4, T>(ring, hf, t);
     }
+    LFT_STAMP(4);
     acc_frags<4, T>(t, f);
     f32x16 y[2];
     zero_acc<2>(y);
     linear_ring<2, 8, T>(ring, f, y);
+    LFT_STAMP(5);
     if (SKIP) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) y[nt] += sk[nt];
     }
     store_acc<2, T>(Y + tok * 64, ok, hh, y);
+    LFT_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------

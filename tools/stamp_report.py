@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Diagnostic: build liblft_hip with -DLFT_STAMPS, run one spatial block, print mean cycles between the
+LFT_STAMP() points of k_spa1 / k_spa2 (wave 0 of each workgroup).  GPU box only; never quote its run time."""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+so = os.path.join(ROOT, "gpurun_out", "liblft_hip_stamps.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLFT_STAMPS",
+                       os.path.join(ROOT, "lft_amd", "csrc", "lft_api.hip"), "-o", so])
+from lft_amd import _lib
+_lib.LIB_PATH = so
+import numpy as np, torch
+from lft_amd.params import deterministic_state
+import gpu_util as G
+L = _lib.lib()
+L.lft_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.lft_debug_clear_stamps.argtypes = []
+A, s, B, h, w = 5, 4, 4, 32, 32
+pk = G.Packed(deterministic_state(64, s, seed=1), A, h, w, s, "bf16", B)
+xin = (torch.randn(B, A * A, h, w, 64, device=G.DEV) * 0.3).to(torch.bfloat16)
+act = pk.new_act()
+nwg = 800
+def run_and_read(which):
+    for _ in range(3):
+        _lib.check(L.lft_spa_block_fwd(pk.buf.data_ptr(), 1, xin.data_ptr(), None, act.data_ptr(), pk.work.data_ptr(), *pk.dims(), G.stream()), "spa")
+    torch.cuda.synchronize()
+    buf = np.zeros(4096 * 16, dtype=np.uint64)
+    _lib.check(L.lft_debug_read_stamps(buf.ctypes.data, buf.size), "read")
+    return buf.reshape(4096, 16)[:nwg, :7].astype(np.int64)
+st = run_and_read(0)     # spa2 runs last, so the buffer holds k_spa2's stamps (same slots as k_spa1)
+d = np.diff(st, axis=1)
+names = ["loads issued->ring init", "wait loads + Wo (32 MFMA)", "LN + frags", "FFN (128 MFMA)", "Wl (16 MFMA)", "stores"]
+print("k_spa2 (stamps of the last launch), mean cycles per phase (s_memtime ticks = shader cycles):")
+for i, nm in enumerate(names):
+    print(f"  {nm:32s} mean {d[:, i].mean():9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}")
+print(f"  total {np.mean(st[:, 6] - st[:, 0]):.0f}; kernel span {st[:, 6].max() - st[:, 0].min()} cycles; first-wave start spread {st[:, 0].max() - st[:, 0].min()}")
