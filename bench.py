@@ -114,9 +114,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from lft_amd import dp
+    rank, local, world = dp.env_world()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
@@ -152,10 +151,7 @@ def main():
         dt = time.perf_counter() - t0
     assert bool(torch.isfinite(out).all())
     note(f"rank {rank}: {args.steps} steps in {dt:.3f} s")
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = dp.barrier_max_seconds(dt, dev)          # MAX over ranks
 
     result = None
     if rank == 0:
