@@ -118,10 +118,12 @@ WorkLayout work_layout(const Dims& d, int prec) {
 }
 
 // Dynamic LDS sizes (bytes) and the opt-in above the 64 KiB default (a workgroup may use all 160 KiB of a CU).
-template <typename T> size_t lds_conv64(int w) { return WRing<T, kConv64Chunk>::LDS_BYTES + ConvIn<T>::bytes(w); }
+template <typename T> size_t lds_conv64(int w) { return WRing<T, kConv64Chunk>::LDS_BYTES + ConvIn<T>::bytes(w) + 4 * TileIO<2, T>::BYTES; }
 constexpr size_t kLdsParams = 1024;   // 256 LayerNorm floats
 template <typename T> size_t lds_spa1(int w) { return WRing<T, kSpaChunk>::LDS_BYTES + ConvIn<T>::bytes(w) + kLdsParams; }
 template <typename T> size_t lds_ring() { return WRing<T, kSpaChunk>::LDS_BYTES + kLdsParams; }
+template <typename T> size_t lds_spa2() { return WRing<T, kSpaChunk>::LDS_BYTES + kLdsParams + 4 * TileIO<4, T>::BYTES; }
+template <typename T> size_t lds_up() { return WRing<T, kSpaChunk>::LDS_BYTES + 4 * TileIO<2, T>::BYTES; }
 template <typename T> size_t lds_ang() { return (size_t)kFragsAng * 1024 * FragInfo<T>::PIECES + kLdsParams; }
 constexpr size_t kMaxLds = 160 * 1024;
 template <typename K> int allow_lds(K kernel, size_t bytes, const char* name) {
@@ -289,10 +291,10 @@ int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, con
     }
     LFT_LAUNCH_OK("k_spa_attn");
     const unsigned nb = blocks_for(d.ntok, 128);
-    if ((rc = allow_lds(k_spa2<T, true>, lds_ring<T>(), "k_spa2"))) return rc;
-    if ((rc = allow_lds(k_spa2<T, false>, lds_ring<T>(), "k_spa2"))) return rc;
-    if (skip) k_spa2<T, true><<<nb, 256, lds_ring<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.ntok);
-    else k_spa2<T, false><<<nb, 256, lds_ring<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, nullptr, out, d.ntok);
+    if ((rc = allow_lds(k_spa2<T, true>, lds_spa2<T>(), "k_spa2"))) return rc;
+    if ((rc = allow_lds(k_spa2<T, false>, lds_spa2<T>(), "k_spa2"))) return rc;
+    if (skip) k_spa2<T, true><<<nb, 256, lds_spa2<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.ntok);
+    else k_spa2<T, false><<<nb, 256, lds_spa2<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, nullptr, out, d.ntok);
     LFT_LAUNCH_OK("k_spa2");
     return 0;
 }
@@ -302,10 +304,10 @@ int upsample(const void* packed, const PackedLayout& L, const T* body, const flo
     float* g = at<float>(ws, W.g);
     const unsigned nb = blocks_for(d.ntok, 128);
     int rc;
-    if ((rc = allow_lds(k_up<T, 1>, lds_ring<T>(), "k_up"))) return rc;
-    if ((rc = allow_lds(k_up<T, 2>, lds_ring<T>(), "k_up"))) return rc;
-    if (d.gt == 1) k_up<T, 1><<<nb, 256, lds_ring<T>(), st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
-    else k_up<T, 2><<<nb, 256, lds_ring<T>(), st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
+    if ((rc = allow_lds(k_up<T, 1>, lds_up<T>(), "k_up"))) return rc;
+    if ((rc = allow_lds(k_up<T, 2>, lds_up<T>(), "k_up"))) return rc;
+    if (d.gt == 1) k_up<T, 1><<<nb, 256, lds_up<T>(), st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
+    else k_up<T, 2><<<nb, 256, lds_up<T>(), st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
     LFT_LAUNCH_OK("k_up");
     const long long npx = (long long)d.B * d.A * d.h * d.s * d.A * d.w * d.s;
     k_assemble<<<blocks_for(npx, 256), 256, 0, st>>>(lr, g, out, d.B, d.A, d.h, d.w, d.s, 1);

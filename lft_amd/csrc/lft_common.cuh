@@ -295,6 +295,135 @@ LFT_DEV void store_acc(T* __restrict__ row, bool ok, int h, const f32x16 (&a)[NT
         }
     }
 }
+// ------------------------------------------------------------------------------------------
+// Coalesced tile I/O.  The accumulator layout gives a lane 4-channel pieces of ONE token row, so a direct wave
+// store touches 32 different rows (32 cache lines) per instruction -- measured 10x slower than the MFMAs it
+// follows.  A wave's 32 tokens are consecutive in memory (one contiguous block of 32 rows), so tiles go
+// through a wave-private LDS scratch, 16 rows at a time: accumulator-layout accesses on one side, 16-byte
+// lane-linear pieces (1 KiB contiguous per wave instruction) on the global-memory side.  Rows are padded
+// by 16 B.  Only the owning wave touches its scratch: LDS operations of one wave execute in order, the wave
+// barrier below only stops the compiler from re-ordering them.
+// ------------------------------------------------------------------------------------------
+template <int NT, typename T> struct TileIO {
+    static constexpr int ROW_BYTES = NT * 32 * (int)sizeof(T);       // a token row in memory
+    static constexpr int ROWB = ROW_BYTES + 16;                       // padded row in scratch
+    static constexpr int PASS_ROWS = 16;
+    static constexpr int BYTES = PASS_ROWS * ROWB;                    // scratch per wave
+    static constexpr int P16 = ROW_BYTES / 16;                        // 16-byte pieces per row
+};
+LFT_DEV void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+LFT_DEV void lds_store4(char* p, f32x4 v, float) { store_raw16(p, __builtin_bit_cast(raw16, v)); }
+LFT_DEV void lds_store4(char* p, f32x4 v, bf16_t) {
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+    *reinterpret_cast<unsigned long long __attribute__((may_alias))*>(p) = __builtin_bit_cast(unsigned long long, o);
+}
+LFT_DEV f32x4 lds_load4(const char* p, float) { return __builtin_bit_cast(f32x4, load_raw16(p)); }
+LFT_DEV f32x4 lds_load4(const char* p, bf16_t) {
+    const bf16x4 v = __builtin_bit_cast(bf16x4, *reinterpret_cast<const unsigned long long __attribute__((may_alias))*>(p));
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+// Store a wave's accumulator tile (32 tokens x NT*32 channels) to `gbase` = row of the tile's first token;
+// rows >= nvalid are not written.
+template <int NT, typename T>
+LFT_DEV void store_tile(T* __restrict__ gbase, int nvalid, int lane, const f32x16 (&a)[NT], char* scr) {
+    using IO = TileIO<NT, T>;
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        wave_lds_fence();                                              // previous pass fully read
+        if ((r >> 4) == pass) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    lds_store4(scr + (r & 15) * IO::ROWB + (32 * nt + 8 * g + 4 * hh) * (int)sizeof(T),
+                               f32x4{a[nt][4 * g], a[nt][4 * g + 1], a[nt][4 * g + 2], a[nt][4 * g + 3]}, T());
+        }
+        wave_lds_fence();
+        char* g0 = reinterpret_cast<char*>(gbase) + (size_t)pass * 16 * IO::ROW_BYTES;
+#pragma unroll
+        for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
+            const int idx = i * 64 + lane, row = idx / IO::P16, pc = idx % IO::P16;
+            const raw16 v = load_raw16(scr + row * IO::ROWB + pc * 16);
+            if (pass * 16 + row < nvalid) store_raw16(g0 + (size_t)idx * 16, v);
+        }
+    }
+}
+
+// Load a wave's tile into the accumulator layout; rows >= nvalid read as zero.  `gbase` must be readable for
+// max(nvalid,1) rows; rows beyond are not touched.
+template <int NT, typename T>
+LFT_DEV void load_tile(const T* __restrict__ gbase, int nvalid, int lane, f32x16 (&a)[NT], char* scr) {
+    using IO = TileIO<NT, T>;
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const char* g0 = reinterpret_cast<const char*>(gbase) + (size_t)pass * 16 * IO::ROW_BYTES;
+        raw16 v[16 * IO::P16 / 64];
+#pragma unroll
+        for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
+            const int idx = i * 64 + lane, row = idx / IO::P16;
+            const bool in = pass * 16 + row < nvalid;
+            const raw16 t = load_raw16(in ? g0 + (size_t)idx * 16 : reinterpret_cast<const char*>(gbase));
+            v[i] = in ? t : raw16{0u, 0u, 0u, 0u};
+        }
+        wave_lds_fence();                                              // previous pass fully consumed
+#pragma unroll
+        for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
+            const int idx = i * 64 + lane;
+            store_raw16(scr + (idx / IO::P16) * IO::ROWB + (idx % IO::P16) * 16, v[i]);
+        }
+        wave_lds_fence();
+        if ((r >> 4) == pass) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 t = lds_load4(scr + (r & 15) * IO::ROWB + (32 * nt + 8 * g + 4 * hh) * (int)sizeof(T), T());
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[nt][4 * g + j] = t[j];
+                }
+        }
+    }
+}
+
+// Load a tile of rows as NATURAL-order B fragments (k = 16 ks + 8 h + j), e.g. the attention output.
+template <int KS, typename T>
+LFT_DEV void load_tile_frags(const T* __restrict__ gbase, int nvalid, int lane, Frag<T> (&f)[KS], char* scr) {
+    using IO = TileIO<KS / 2, T>;
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const char* g0 = reinterpret_cast<const char*>(gbase) + (size_t)pass * 16 * IO::ROW_BYTES;
+        raw16 v[16 * IO::P16 / 64];
+#pragma unroll
+        for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
+            const int idx = i * 64 + lane, row = idx / IO::P16;
+            const bool in = pass * 16 + row < nvalid;
+            const raw16 t = load_raw16(in ? g0 + (size_t)idx * 16 : reinterpret_cast<const char*>(gbase));
+            v[i] = in ? t : raw16{0u, 0u, 0u, 0u};
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
+            const int idx = i * 64 + lane;
+            store_raw16(scr + (idx / IO::P16) * IO::ROWB + (idx % IO::P16) * 16, v[i]);
+        }
+        wave_lds_fence();
+        if ((r >> 4) == pass) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) f[ks] = lds_row8(scr + (r & 15) * IO::ROWB + (16 * ks + 8 * hh) * (int)sizeof(T), true, T());
+        }
+    }
+}
+
 template <int NT>
 LFT_DEV void zero_acc(f32x16 (&a)[NT]) {
 #pragma unroll

@@ -180,10 +180,12 @@ __global__ __launch_bounds__(256) void k_conv64(const T* __restrict__ in, T* __r
     const int im = blockIdx.x / tpi, p0 = (blockIdx.x % tpi) * 128;
     const int tl = wave * 32 + r, p = p0 + tl;
     const bool ok = p < hw;
-    const size_t off = ((size_t)im * hw + min(p, hw - 1)) * 64;
-    f32x16 rr[2];
-    if (RES) load_acc<2, T>(res + off, ok, hh, rr);           // issued first: its latency hides under the whole tile
+    const int t0 = p0 + wave * 32, nvalid = max(0, min(32, hw - t0));                 // this wave's 32 consecutive tokens
+    const size_t tile_off = ((size_t)im * hw + min(t0, hw - 1)) * 64;
     char* lds_in = smem + WRing<T, kConv64Chunk>::LDS_BYTES;
+    char* scr = lds_in + ConvIn<T>::bytes(w) + wave * TileIO<2, T>::BYTES;            // wave-private tile I/O scratch
+    f32x16 rr[2];
+    if (RES) load_tile<2, T>(res + tile_off, nvalid, lane, rr, scr);                  // first: its latency hides under the tile
     WRing<T, kConv64Chunk> ring;
     ring.init(wstream, smem, 72);
     stage_conv_input<T>(in + (size_t)im * hw * 64, p0, hw, w, lds_in);
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void k_conv64(const T* __restrict__ in, T* __r
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[nt] += rr[nt];
     }
-    store_acc<2, T>(out + off, ok, hh, acc);
+    store_tile<2, T>(out + tile_off, nvalid, lane, acc, scr);
 }
 
 // ------------------------------------------------------------------------------------------

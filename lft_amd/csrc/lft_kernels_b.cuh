@@ -43,8 +43,12 @@ __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const 
         store_acc<4, float>(pe_out + (size_t)pc * 128, ok, hh, t);
         return;
     }
-    const size_t off = ((size_t)im * hw + pc) * 128;
-    store_acc<4, T>(TOK + off, ok, hh, t);
+    // Tile I/O scratch aliases the (now dead) conv input tile: every wave must be done reading it first.
+    __syncthreads();
+    const int t0 = p0 + wave * 32, nvalid = max(0, min(32, hw - t0));
+    const size_t tile_off = ((size_t)im * hw + min(t0, hw - 1)) * 128;
+    char* scr = lds_in + wave * TileIO<4, T>::BYTES;
+    store_tile<4, T>(TOK + tile_off, nvalid, lane, t, scr);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] += t[nt];
     layernorm_acc<4>(n, lds_ln, lds_ln + 128, hh);
@@ -55,17 +59,17 @@ __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const 
         f32x16 a[4];
         zero_acc<4>(a);
         linear_ring<4, 8, T>(ring, nf, a);
-        store_acc<4, T>(Q + off, ok, hh, a);
+        store_tile<4, T>(Q + tile_off, nvalid, lane, a, scr);
         zero_acc<4>(a);
         linear_ring<4, 8, T>(ring, nf, a);
-        store_acc<4, T>(K + off, ok, hh, a);
+        store_tile<4, T>(K + tile_off, nvalid, lane, a, scr);
     }
     LFT_STAMP(4);
     acc_frags<4, T>(t, nf);
     zero_acc<4>(n);
     linear_ring<4, 8, T>(ring, nf, n);
     LFT_STAMP(5);
-    store_acc<4, T>(Vv + off, ok, hh, n);
+    store_tile<4, T>(Vv + tile_off, nvalid, lane, n, scr);
     LFT_STAMP(6);
 }
 
@@ -297,29 +301,30 @@ __global__ __launch_bounds__(256, 2) void k_spa2(const T* __restrict__ TOK, cons
                                               long long ntok) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const long long tok_raw = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + r;
-    const bool ok = tok_raw < ntok;
-    const long long tok = ok ? tok_raw : ntok - 1;
-    LFT_STAMP(0);
+    const int wave = threadIdx.x >> 6;
+    const long long t0 = ((long long)blockIdx.x * 4 + wave) * 32;                     // this wave's 32 consecutive tokens
+    const int nvalid = (int)max(0LL, min(32LL, ntok - t0));
+    const long long tb = min(t0, ntok - 1);
+    char* scr = smem + WRing<T, kSpaChunk>::LDS_BYTES + 1024 + wave * TileIO<4, T>::BYTES;   // wave-private tile I/O scratch
+    LFT_STAMP(8);
     f32x16 t[4], n[4];
-    load_acc<4, T>(TOK + tok * 128, ok, hh, t);
+    load_tile<4, T>(TOK + tb * 128, nvalid, lane, t, scr);
     Frag<T> f[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) f[ks] = load_row8(O + tok * 128 + 16 * ks + 8 * hh, ok, T());
+    load_tile_frags<8, T>(O + tb * 128, nvalid, lane, f, scr);
     f32x16 sk[2];
-    if (SKIP) load_acc<2, T>(skip + tok * 64, ok, hh, sk);
+    if (SKIP) load_tile<2, T>(skip + tb * 64, nvalid, lane, sk, scr);
     float* lds_ln = reinterpret_cast<float*>(smem + WRing<T, kSpaChunk>::LDS_BYTES);
     stage_params(ln + 256, lds_ln, 256);                              // feed_forward.0.{weight,bias}; published by the first ring barrier
     WRing<T, kSpaChunk> ring;
     ring.init(ws, smem, 176);
-    LFT_STAMP(1);
+    LFT_STAMP(9);
     linear_ring<4, 8, T>(ring, f, t);
-    LFT_STAMP(2);
+    LFT_STAMP(10);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] = t[nt];
     layernorm_acc<4>(n, lds_ln, lds_ln + 128, hh);
     acc_frags<4, T>(n, f);
-    LFT_STAMP(3);
+    LFT_STAMP(11);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         f32x16 hid[2];
@@ -333,18 +338,18 @@ __global__ __launch_bounds__(256, 2) void k_spa2(const T* __restrict__ TOK, cons
         acc_frags<2, T>(hid, hf);
         linear_ring<4, 4, T>(ring, hf, t);
     }
-    LFT_STAMP(4);
+    LFT_STAMP(12);
     acc_frags<4, T>(t, f);
     f32x16 y[2];
     zero_acc<2>(y);
     linear_ring<2, 8, T>(ring, f, y);
-    LFT_STAMP(5);
+    LFT_STAMP(13);
     if (SKIP) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) y[nt] += sk[nt];
     }
-    store_acc<2, T>(Y + tok * 64, ok, hh, y);
-    LFT_STAMP(6);
+    store_tile<2, T>(Y + tb * 64, nvalid, lane, y, scr);
+    LFT_STAMP(14);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -363,8 +368,11 @@ __global__ __launch_bounds__(256) void k_up(const T* __restrict__ X, const T* __
     const long long tok_raw = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + r;
     const bool ok = tok_raw < ntok;
     const long long tok = ok ? tok_raw : ntok - 1;
+    const long long t0 = tok_raw - r;
+    const int nvalid = (int)max(0LL, min(32LL, ntok - t0));
+    char* scr = smem + WRing<T, kSpaChunk>::LDS_BYTES + (threadIdx.x >> 6) * TileIO<2, T>::BYTES;
     f32x16 x[2];
-    load_acc<2, T>(X + tok * 64, ok, hh, x);
+    load_tile<2, T>(X + min(t0, ntok - 1) * 64, nvalid, lane, x, scr);
     WRing<T, kSpaChunk> ring;
     ring.init(ws, smem, nchunk * (4 + 2 * GT));
     Frag<T> xf[4];

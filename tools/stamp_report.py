@@ -26,11 +26,13 @@ def run_and_read(which):
     torch.cuda.synchronize()
     buf = np.zeros(4096 * 16, dtype=np.uint64)
     _lib.check(L.lft_debug_read_stamps(buf.ctypes.data, buf.size), "read")
-    return buf.reshape(4096, 16)[:nwg, :7].astype(np.int64)
-st = run_and_read(0)     # spa2 runs last, so the buffer holds k_spa2's stamps (same slots as k_spa1)
-d = np.diff(st, axis=1)
-names = ["loads issued->ring init", "wait loads + Wo (32 MFMA)", "LN + frags", "FFN (128 MFMA)", "Wl (16 MFMA)", "stores"]
-print("k_spa2 (stamps of the last launch), mean cycles per phase (s_memtime ticks = shader cycles):")
-for i, nm in enumerate(names):
-    print(f"  {nm:32s} mean {d[:, i].mean():9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}")
-print(f"  total {np.mean(st[:, 6] - st[:, 0]):.0f}; kernel span {st[:, 6].max() - st[:, 0].min()} cycles; first-wave start spread {st[:, 0].max() - st[:, 0].min()}")
+    return buf.reshape(4096, 16)[:nwg].astype(np.int64)
+allst = run_and_read(0)
+def report(title, st, names):
+    d = np.diff(st, axis=1)
+    print(title + ": mean cycles per phase, wave 0 of each workgroup (s_memtime ticks):")
+    for i, nm in enumerate(names):
+        print(f"  {nm:40s} mean {d[:, i].mean():9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}")
+    print(f"  total {np.mean(st[:, -1] - st[:, 0]):.0f}")
+report("k_spa1", allst[:, 0:7], ["petok loads + ring init + stage input", "conv 64->128 (144 MFMA, 9 chunks)", "store tok, +PE, LN, frags", "Q, K (64 MFMA) + stores", "V frags + V (32 MFMA)", "store V"])
+report("k_spa2", allst[:, 8:15], ["loads issued->ring init", "wait loads + Wo (32 MFMA)", "LN + frags", "FFN (128 MFMA)", "Wl (16 MFMA)", "stores"])
