@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(HERE, "liblft_hip.so")
+LIB_PATH = os.environ.get("LFT_LIB_PATH") or os.path.join(HERE, "liblft_hip.so")   # LFT_LIB_PATH: experiment builds (tools/ab_build.py)
 SOURCES = ["lft_api.hip", "lft_common.cuh", "lft_kernels_a.cuh", "lft_kernels_b.cuh"]
 
 PREC_F32, PREC_BF16 = 0, 1

@@ -207,9 +207,9 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
         {   // spatial part 1: token embedding conv + in_proj
             std::vector<PackOp> ops;
             conv_ops(ops, q[0], 128);
-            ops.push_back(lin_op(q[3], 0, 128, 128, 0, 8, 1, kSpaScale));
-            ops.push_back(lin_op(q[3], 128, 128, 128, 0, 8, 1, 1.0f));
-            ops.push_back(lin_op(q[3], 256, 128, 128, 0, 8, 1, 1.0f));
+            ops.push_back(lin_op(q[3], 256, 128, 128, 0, 8, 1, 1.0f));          // Wv (consumed first)
+            ops.push_back(lin_op(q[3], 0, 128, 128, 0, 8, 1, kSpaScale));      // Wq
+            ops.push_back(lin_op(q[3], 128, 128, 128, 0, 8, 1, 1.0f));          // Wk
             if ((rc = run_pack<T>(ops, at<T>(packed, L.s_spa1[l]), kFragsSpa1, st))) return rc;
         }
         {   // spatial part 2: out_proj (operand from memory: natural k), FFN in 4 chunks, 1x1x1 conv
@@ -242,6 +242,12 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
     return 0;
 }
 
+void launch_assemble(const float* lr, const float* g, float* out, int B, int A, int h, int w, int s, int with_body, hipStream_t st) {
+    const dim3 grid((unsigned)((A * w * s + 255) / 256), (unsigned)(A * h * s), (unsigned)B);
+    if (s == 2) k_assemble<2><<<grid, 256, 0, st>>>(lr, g, out, B, A, h, w, with_body);
+    else k_assemble<4><<<grid, 256, 0, st>>>(lr, g, out, B, A, h, w, with_body);
+}
+
 // ---------------------------------------------------------------------------- stages
 template <typename T>
 int init_features(const void* packed, const PackedLayout& L, const float* lr, T* x0, T* ta, T* tb, T* feat, const Dims& d, hipStream_t st) {
@@ -250,7 +256,7 @@ int init_features(const void* packed, const PackedLayout& L, const float* lr, T*
     int rc;
     if ((rc = allow_lds(k_conv64<T, false>, lds, "k_conv64"))) return rc;
     if ((rc = allow_lds(k_conv64<T, true>, lds, "k_conv64"))) return rc;
-    k_conv0<T><<<blocks_for(d.ntok * 8, 256), 256, 0, st>>>(lr, at<float>(packed, L.conv0_w), x0, d.B, d.A, d.h, d.w);
+    k_conv0<T><<<dim3((unsigned)((d.hw + 31) / 32), (unsigned)nimg), 256, 0, st>>>(lr, at<float>(packed, L.conv0_w), x0, d.B, d.A, d.h, d.w);
     LFT_LAUNCH_OK("k_conv0");
     k_conv64<T, false><<<nwg, 256, lds, st>>>(x0, ta, nullptr, at<T>(packed, L.s_conv[0]), nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_conv64");
@@ -309,8 +315,7 @@ int upsample(const void* packed, const PackedLayout& L, const T* body, const flo
     if (d.gt == 1) k_up<T, 1><<<nb, 256, lds_up<T>(), st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
     else k_up<T, 2><<<nb, 256, lds_up<T>(), st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
     LFT_LAUNCH_OK("k_up");
-    const long long npx = (long long)d.B * d.A * d.h * d.s * d.A * d.w * d.s;
-    k_assemble<<<blocks_for(npx, 256), 256, 0, st>>>(lr, g, out, d.B, d.A, d.h, d.w, d.s, 1);
+    launch_assemble(lr, g, out, d.B, d.A, d.h, d.w, d.s, 1, st);
     LFT_LAUNCH_OK("k_assemble");
     return 0;
 }
@@ -402,8 +407,7 @@ int lft_bicubic_fwd(const float* lr, float* out, int B, int A, int h, int w, int
     Dims d; int rc;
     if (!lr || !out) return fail(LFT_ERR_ARG, "null pointer");
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
-    const long long npx = (long long)B * A * h * s * A * w * s;
-    k_assemble<<<blocks_for(npx, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(lr, nullptr, out, B, A, h, w, s, 0);
+    launch_assemble(lr, nullptr, out, B, A, h, w, s, 0, static_cast<hipStream_t>(stream));
     LFT_LAUNCH_OK("k_assemble");
     return 0;
 }

@@ -151,6 +151,28 @@ LFT_DEV void glds_piece(const char* __restrict__ gsrc, char* lds_dst, int lane) 
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// s_waitcnt vmcnt(n) for a value that is a compile-time constant after inlining (the switch folds away).
+#define LFT_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+LFT_DEV void wait_vmcnt(int n) {
+    switch (n < 0 ? 0 : (n > 63 ? 63 : n)) {
+        LFT_VMCNT_CASE(0) LFT_VMCNT_CASE(1) LFT_VMCNT_CASE(2) LFT_VMCNT_CASE(3) LFT_VMCNT_CASE(4) LFT_VMCNT_CASE(5) LFT_VMCNT_CASE(6) LFT_VMCNT_CASE(7)
+        LFT_VMCNT_CASE(8) LFT_VMCNT_CASE(9) LFT_VMCNT_CASE(10) LFT_VMCNT_CASE(11) LFT_VMCNT_CASE(12) LFT_VMCNT_CASE(13) LFT_VMCNT_CASE(14) LFT_VMCNT_CASE(15)
+        LFT_VMCNT_CASE(16) LFT_VMCNT_CASE(17) LFT_VMCNT_CASE(18) LFT_VMCNT_CASE(19) LFT_VMCNT_CASE(20) LFT_VMCNT_CASE(21) LFT_VMCNT_CASE(22) LFT_VMCNT_CASE(23)
+        LFT_VMCNT_CASE(24) LFT_VMCNT_CASE(25) LFT_VMCNT_CASE(26) LFT_VMCNT_CASE(27) LFT_VMCNT_CASE(28) LFT_VMCNT_CASE(29) LFT_VMCNT_CASE(30) LFT_VMCNT_CASE(31)
+        LFT_VMCNT_CASE(32) LFT_VMCNT_CASE(33) LFT_VMCNT_CASE(34) LFT_VMCNT_CASE(35) LFT_VMCNT_CASE(36) LFT_VMCNT_CASE(37) LFT_VMCNT_CASE(38) LFT_VMCNT_CASE(39)
+        LFT_VMCNT_CASE(40) LFT_VMCNT_CASE(41) LFT_VMCNT_CASE(42) LFT_VMCNT_CASE(43) LFT_VMCNT_CASE(44) LFT_VMCNT_CASE(45) LFT_VMCNT_CASE(46) LFT_VMCNT_CASE(47)
+        LFT_VMCNT_CASE(48) LFT_VMCNT_CASE(49) LFT_VMCNT_CASE(50) LFT_VMCNT_CASE(51) LFT_VMCNT_CASE(52) LFT_VMCNT_CASE(53) LFT_VMCNT_CASE(54) LFT_VMCNT_CASE(55)
+        LFT_VMCNT_CASE(56) LFT_VMCNT_CASE(57) LFT_VMCNT_CASE(58) LFT_VMCNT_CASE(59) LFT_VMCNT_CASE(60) LFT_VMCNT_CASE(61) LFT_VMCNT_CASE(62) LFT_VMCNT_CASE(63)
+    }
+}
+
+// Workgroup barrier that does NOT drain vector memory: own LDS operations complete (lgkmcnt(0)), then s_barrier.
+// __syncthreads() makes hipcc wait vmcnt(0) whenever LDS-DMA is outstanding, which serialises the ring's
+// 2-chunk lookahead and forces every in-flight output store to be acknowledged at each chunk boundary.  The
+// "memory" clobber keeps the compiler from moving LDS/global accesses across it; LDS-DMA completion is handled
+// explicitly by the counted wait in WRing.
+LFT_DEV void wg_barrier_keep_vm() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Weight ring: the 4 waves of a workgroup consume the same fragment stream in lock-step.  The stream is cut
 // into chunks of CH fragments held in a 3-slot LDS ring: while chunk c feeds the MFMAs, chunks c+1 and c+2 are
 // in flight / landed (LDS-DMA issued two chunks ahead: one chunk of MFMAs, ~0.25 us, is shorter than the
@@ -174,13 +196,22 @@ struct WRing {
     const char* g;
     char* lds;
     int lane, wave, pos, nfrag;
-    LFT_MEM void init(const T* stream, char* lds_base, int total_frags) {
+    // Exact accounting of VM operations younger than the chunk being published (stores count in vmcnt and take
+    // microseconds to be acknowledged; forcing them complete at every chunk barrier cost more than the MFMAs).
+    // A kernel may note_vm(n) the wave-level VM instructions it issued since the last chunk barrier -- only when
+    // they are certain to have been issued (`exact` = every tile of the workgroup is full, so no predicated store
+    // is skipped).  Under-counting is always safe (the wait only gets stricter); over-counting is not.
+    int vm_cur, vm_prev;
+    bool exact;
+    LFT_MEM void init(const T* stream, char* lds_base, int total_frags, bool exact_counts = false) {
         g = reinterpret_cast<const char*>(stream); lds = lds_base; nfrag = total_frags; pos = 0;
         lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        vm_cur = 0; vm_prev = 0; exact = exact_counts;
         issue(0);
         issue(1);
     }
+    LFT_MEM void note_vm(int n) { vm_cur += n; }
     // Every wave issues exactly PIECES_PER_WAVE DMA instructions per chunk (clamped to the last piece of the
     // stream when the chunk is short) so that the counted wait below is exact.
     LFT_MEM void issue(int c) {
@@ -194,24 +225,19 @@ struct WRing {
             glds_piece(src + piece * 1024, dst + piece * 1024, lane);
         }
     }
+    // Chunk c's DMA was issued right after barrier c-2.  Younger than it: the VM ops noted in the two intervals
+    // since, and the DMA of chunk c+1 (if it exists).
     LFT_MEM void wait_landed(bool next_in_flight) {
-        if (next_in_flight) {
-            if constexpr (PIECES_PER_WAVE == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if constexpr (PIECES_PER_WAVE == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if constexpr (PIECES_PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if constexpr (PIECES_PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if constexpr (PIECES_PER_WAVE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if constexpr (PIECES_PER_WAVE == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        const int base = next_in_flight ? PIECES_PER_WAVE : 0;
+        if (exact) wait_vmcnt(base + vm_prev + vm_cur);
+        else wait_vmcnt(base);
+        vm_prev = vm_cur; vm_cur = 0;
     }
     LFT_MEM Frag<T> next() {
         const int c = pos / CH, i = pos % CH;
         if (i == 0) {
             wait_landed((c + 1) * CH < nfrag);
-            __syncthreads();
+            wg_barrier_keep_vm();
             issue(c + 2);
         }
         ++pos;
@@ -332,7 +358,7 @@ LFT_DEV f32x4 lds_load4(const char* p, bf16_t) {
 // Store a wave's accumulator tile (32 tokens x NT*32 channels) to `gbase` = row of the tile's first token;
 // rows >= nvalid are not written.
 template <int NT, typename T>
-LFT_DEV void store_tile(T* __restrict__ gbase, int nvalid, int lane, const f32x16 (&a)[NT], char* scr) {
+LFT_DEV int store_tile(T* __restrict__ gbase, int nvalid, int lane, const f32x16 (&a)[NT], char* scr) {
     using IO = TileIO<NT, T>;
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -352,9 +378,14 @@ LFT_DEV void store_tile(T* __restrict__ gbase, int nvalid, int lane, const f32x1
         for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
             const int idx = i * 64 + lane, row = idx / IO::P16, pc = idx % IO::P16;
             const raw16 v = load_raw16(scr + row * IO::ROWB + pc * 16);
+#ifndef LFT_EXP_NO_TILE_STORES           // experiment build only (tools/ab_build.py): results are wrong on purpose
             if (pass * 16 + row < nvalid) store_raw16(g0 + (size_t)idx * 16, v);
+#else
+            asm volatile("" :: "v"(v));
+#endif
         }
     }
+    return 2 * (16 * IO::P16 / 64);        // wave-level global store instructions issued when the tile is full
 }
 
 // Load a wave's tile into the accumulator layout; rows >= nvalid read as zero.  `gbase` must be readable for

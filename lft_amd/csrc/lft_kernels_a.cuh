@@ -83,30 +83,33 @@ __global__ void k_copy_f32(const float* __restrict__ src, float* __restrict__ ds
 template <typename T>
 __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, const float* __restrict__ w0,
                                                T* __restrict__ out, int B, int A, int h, int w) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long tok = idx >> 3;
-    const int cg = (int)(idx & 7);
-    const int V = A * A, hw = h * w;
-    if (tok >= (long long)B * V * hw) return;
-    const int p = (int)(tok % hw), v = (int)((tok / hw) % V), b = (int)(tok / ((long long)hw * V));
-    const int y = p / w, x = p % w, a1 = v / A, a2 = v % A;
+    // grid: x = 32-token groups of one view image, y = image (b, v).  32-bit index math only.
+    __shared__ float wl[576];                                        // the 64 x 9 weights, read 72 times per thread
+    for (int i = threadIdx.x; i < 576; i += 256) wl[i] = w0[i];
+    __syncthreads();
+    const int hw = h * w, im = blockIdx.y, V = A * A;
+    const int p = blockIdx.x * 32 + (threadIdx.x >> 3), cg = threadIdx.x & 7;
+    if (p >= hw) return;
+    const int b = im / V, v = im - b * V;
+    const int y = p / w, x = p - y * w, a1 = v / A, a2 = v - a1 * A;
     const float* img = lr + (size_t)b * (A * h) * (A * w) + (size_t)(a1 * h) * (A * w) + a2 * w;
     float val[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-        val[t] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[(size_t)yy * (A * w) + xx] : 0.0f;
+        val[t] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[yy * (A * w) + xx] : 0.0f;
     }
     f32x4 o[2];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float a = 0.0f;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) a += w0[(cg * 8 + c) * 9 + t] * val[t];
+        for (int t = 0; t < 9; ++t) a += wl[(cg * 8 + c) * 9 + t] * val[t];
         o[c >> 2][c & 3] = a;
     }
-    store4(out + tok * 64 + cg * 8, o[0]);
-    store4(out + tok * 64 + cg * 8 + 4, o[1]);
+    T* row = out + ((size_t)im * hw + p) * 64 + cg * 8;
+    store4(row, o[0]);
+    store4(row + 4, o[1]);
 }
 
 // ------------------------------------------------------------------------------------------

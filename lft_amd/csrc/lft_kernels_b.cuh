@@ -9,7 +9,7 @@
 //   tok = conv3x3(x; MLP.weight as [128,64,3,3])            (unfold + Linear 576->128)
 //   n   = LN(tok + PEtok[p])                                 (PEtok = same embedding of the position image, cached)
 //   Q = n Wq^T (pre-scaled by 1/4 * log2 e), K = n Wk^T, V = tok Wv^T
-// Stream: conv[36 x 4] Wq[4x8] Wk[4x8] Wv[4x8]  (240 fragments).
+// Stream: conv[36 x 4] Wv[4x8] Wq[4x8] Wk[4x8]  (240 fragments).
 // PE_ONLY: embed the position image itself and write fp32 tokens (pack-time precompute).
 // ------------------------------------------------------------------------------------------
 constexpr int kSpaChunk = 16;   // fragments per ring chunk: one conv tap (4 k-steps x 4 row tiles), half an in_proj matrix
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const 
     float* lds_ln = reinterpret_cast<float*>(lds_in + ConvIn<T>::bytes(w));
     if (!PE_ONLY) stage_params(ln, lds_ln, 256);                      // norm.{weight,bias}; published by the staging barrier
     WRing<T, kSpaChunk> ring;
-    ring.init(ws, smem, PE_ONLY ? 144 : 240);
+    ring.init(ws, smem, PE_ONLY ? 144 : 240, p0 + 128 <= hw);
     stage_conv_input<T>(X + (size_t)im * hw * 64, p0, hw, w, lds_in);
     LFT_STAMP(1);
     f32x16 t[4];
@@ -48,28 +48,31 @@ __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const 
     const int t0 = p0 + wave * 32, nvalid = max(0, min(32, hw - t0));
     const size_t tile_off = ((size_t)im * hw + min(t0, hw - 1)) * 128;
     char* scr = lds_in + wave * TileIO<4, T>::BYTES;
-    store_tile<4, T>(TOK + tile_off, nvalid, lane, t, scr);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) n[nt] += t[nt];
-    layernorm_acc<4>(n, lds_ln, lds_ln + 128, hh);
+    ring.note_vm(store_tile<4, T>(TOK + tile_off, nvalid, lane, t, scr));
     Frag<T> nf[8];
-    acc_frags<4, T>(n, nf);
-    LFT_STAMP(3);
+    {   // V = tok Wv^T first (raw tokens, reference LFT.py:185), so that tok can then be normalised in place
+        acc_frags<4, T>(t, nf);
+        f32x16 a[4];
+        zero_acc<4>(a);
+        linear_ring<4, 8, T>(ring, nf, a);
+        LFT_STAMP(3);
+        ring.note_vm(store_tile<4, T>(Vv + tile_off, nvalid, lane, a, scr));
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) t[nt] += n[nt];
+    layernorm_acc<4>(t, lds_ln, lds_ln + 128, hh);
+    acc_frags<4, T>(t, nf);
+    LFT_STAMP(4);
     {
         f32x16 a[4];
         zero_acc<4>(a);
         linear_ring<4, 8, T>(ring, nf, a);
-        store_tile<4, T>(Q + tile_off, nvalid, lane, a, scr);
+        ring.note_vm(store_tile<4, T>(Q + tile_off, nvalid, lane, a, scr));
         zero_acc<4>(a);
         linear_ring<4, 8, T>(ring, nf, a);
+        LFT_STAMP(5);
         store_tile<4, T>(K + tile_off, nvalid, lane, a, scr);
     }
-    LFT_STAMP(4);
-    acc_frags<4, T>(t, nf);
-    zero_acc<4>(n);
-    linear_ring<4, 8, T>(ring, nf, n);
-    LFT_STAMP(5);
-    store_tile<4, T>(Vv + tile_off, nvalid, lane, n, scr);
     LFT_STAMP(6);
 }
 
@@ -434,29 +437,37 @@ LFT_DEV float bicubic_at(const float* __restrict__ view, int stride, int h, int 
     }
     return acc;
 }
+template <int S>
 __global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ lr, const float* __restrict__ G, float* __restrict__ out,
-                                                  int B, int A, int h, int w, int s, int with_body) {
-    const int HR_H = A * h * s, HR_W = A * w * s;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)B * HR_H * HR_W) return;
-    const int X = (int)(idx % HR_W), Y = (int)((idx / HR_W) % HR_H), b = (int)(idx / ((long long)HR_W * HR_H));
-    const int a1 = Y / (h * s), a2 = X / (w * s);
+                                                  int B, int A, int h, int w, int with_body) {
+    // grid: x = 256-pixel column groups, y = HR mosaic row, z = batch.  Row quantities are block-uniform (scalar),
+    // S is a compile-time power of two, so the per-thread index math has a single division (view column).
+    const int HR_H = A * h * S, HR_W = A * w * S;
+    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y, b = blockIdx.z;
+    if (X >= HR_W) return;
+    const int a1 = Y / (h * S), a2 = X / (w * S);
     const float* view = lr + (size_t)b * (A * h) * (A * w) + (size_t)(a1 * h) * (A * w) + a2 * w;
-    float v = bicubic_at(view, A * w, h, w, Y - a1 * h * s, X - a2 * w * s, s);
+    float v = bicubic_at(view, A * w, h, w, Y - a1 * h * S, X - a2 * w * S, S);
     if (with_body) {
-        const int gp = (s + 2) * (s + 2), hw = h * w, V = A * A;
-        const int qy = Y / s, qx = X / s, i = Y % s, j = X % s;
+        constexpr int GP = (S + 2) * (S + 2);
+        const int hw = h * w, V = A * A;
+        const int qy = Y / S, qx = X / S, i = Y % S, j = X % S;
+        const float* Gb = G + (size_t)b * V * hw * GP;
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int I = i - S * dy, by = qy + dy;
+            if (I < -1 || I > S || by < 0 || by >= A * h) continue;
+            const int vy = by / h, py = by - vy * h;
 #pragma unroll
             for (int dx = -1; dx <= 1; ++dx) {
-                const int I = i - s * dy, J = j - s * dx, by = qy + dy, bx = qx + dx;
-                if (I < -1 || I > s || J < -1 || J > s || by < 0 || by >= A * h || bx < 0 || bx >= A * w) continue;
-                const int vv = (by / h) * A + bx / w, pp = (by % h) * w + bx % w;
-                v += G[(((size_t)b * V + vv) * hw + pp) * gp + (I + 1) * (s + 2) + (J + 1)];
+                const int J = j - S * dx, bx = qx + dx;
+                if (J < -1 || J > S || bx < 0 || bx >= A * w) continue;
+                const int vx = bx / w, px = bx - vx * w;
+                v += Gb[((size_t)(vy * A + vx) * hw + py * w + px) * GP + (I + 1) * (S + 2) + (J + 1)];
             }
+        }
     }
-    out[idx] = v;
+    out[((size_t)b * HR_H + Y) * HR_W + X] = v;
 }
 
 // ------------------------------------------------------------------------------------------
