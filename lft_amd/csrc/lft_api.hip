@@ -87,7 +87,7 @@ PackedLayout packed_layout(const Dims& d, int prec) {
     L.conv0_w = take(576 * 4);
     for (int l = 0; l < kLayers; ++l) { L.ln_ang[l] = take(256 * 4); L.ln_spa[l] = take(512 * 4); }
     L.ang_pe = take((size_t)d.V * 64 * 4);
-    for (int l = 0; l < kLayers; ++l) L.petok[l] = take((size_t)d.hw * 128 * 4);
+    for (int l = 0; l < kLayers; ++l) L.petok[l] = take((size_t)d.hw * 128 * esz);
     L.spa_pe_img = take((size_t)d.hw * 64 * esz);
     for (int i = 0; i < 3; ++i) L.s_conv[i] = take(kFragsConv * fragb);
     for (int l = 0; l < kLayers; ++l) {
@@ -222,11 +222,11 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
             ops.push_back(lin_op(q[9], 0, 64, 128, 0, 8, 1, 1.0f));
             if ((rc = run_pack<T>(ops, at<T>(packed, L.s_spa2[l]), kFragsSpa2, st))) return rc;
         }
-        // embedded spatial position tokens of this layer (reference LFT.py:180), fp32 [h*w][128]
+        // embedded spatial position tokens of this layer (reference LFT.py:180), [h*w][128] in the activation type
         if ((rc = allow_lds(k_spa1<T, true>, lds_spa1<T>(d.w), "k_spa1"))) return rc;
         k_spa1<T, true><<<(d.hw + 127) / 128, 256, lds_spa1<T>(d.w), st>>>(
             at<T>(packed, L.spa_pe_img), at<T>(packed, L.s_spa1[l]), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-            at<float>(packed, L.petok[l]), 1, d.h, d.w);
+            at<T>(packed, L.petok[l]), 1, d.h, d.w);
         LFT_LAUNCH_OK("k_spa1<pe>");
     }
     {   // up-sampler: per 32-row chunk of the 1x1 conv, followed by the matching columns of the overlap-add matrix
@@ -286,7 +286,7 @@ int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, con
     const float* ln = at<float>(packed, L.ln_spa[l]);
     int rc;
     if ((rc = allow_lds(k_spa1<T, false>, lds_spa1<T>(d.w), "k_spa1"))) return rc;
-    k_spa1<T, false><<<nwg, 256, lds_spa1<T>(d.w), st>>>(in, at<T>(packed, L.s_spa1[l]), ln, at<float>(packed, L.petok[l]),
+    k_spa1<T, false><<<nwg, 256, lds_spa1<T>(d.w), st>>>(in, at<T>(packed, L.s_spa1[l]), ln, at<T>(packed, L.petok[l]),
                                                          tok, q, k, v, nullptr, nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_spa1");
     if constexpr (sizeof(T) == 2) {

@@ -309,6 +309,28 @@ LFT_DEV void load_acc(const T* __restrict__ row, bool ok, int h, f32x16 (&a)[NT]
         }
     }
 }
+// Raw (unconverted) accumulator-layout pieces of a token row, for values that are loaded early but used late:
+// a bf16 row costs half the registers of its fp32 expansion while it waits.
+template <typename T> struct RawPiece;
+template <> struct RawPiece<float> { typedef f32x4 type; };
+template <> struct RawPiece<bf16_t> { typedef bf16x4 type; };
+template <int NT, typename T>
+LFT_DEV void load_acc_raw(const T* __restrict__ row, int h, typename RawPiece<T>::type (&p)[NT * 4]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) p[nt * 4 + g] = *reinterpret_cast<const typename RawPiece<T>::type*>(row + 32 * nt + 8 * g + 4 * h);
+}
+template <int NT, typename T>
+LFT_DEV void add_acc_raw(f32x16 (&a)[NT], const typename RawPiece<T>::type (&p)[NT * 4], bool ok) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[nt][4 * g + j] += ok ? (float)p[nt * 4 + g][j] : 0.0f;
+}
+
 template <int NT, typename T>
 LFT_DEV void store_acc(T* __restrict__ row, bool ok, int h, const f32x16 (&a)[NT]) {
     if (!ok) return;
@@ -337,10 +359,14 @@ template <int NT, typename T> struct TileIO {
     static constexpr int BYTES = PASS_ROWS * ROWB;                    // scratch per wave
     static constexpr int P16 = ROW_BYTES / 16;                        // 16-byte pieces per row
 };
+// The LDS queue serves one wave's instructions in issue order, so a ds_read issued after a ds_write of the same
+// wave sees it whichever lane wrote it: only the COMPILER must be kept from re-ordering them.  (A wavefront-
+// scope C++ fence is not free here: hipcc lowered it to s_waitcnt vmcnt(0), i.e. every pass waited for the
+// previous pass's global stores to be acknowledged -- 3.5k cycles per tile store.)
 LFT_DEV void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
 }
 LFT_DEV void lds_store4(char* p, f32x4 v, float) { store_raw16(p, __builtin_bit_cast(raw16, v)); }
 LFT_DEV void lds_store4(char* p, f32x4 v, bf16_t) {
@@ -355,11 +381,14 @@ LFT_DEV f32x4 lds_load4(const char* p, bf16_t) {
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 
-// Store a wave's accumulator tile (32 tokens x NT*32 channels) to `gbase` = row of the tile's first token;
-// rows >= nvalid are not written.
-template <int NT, typename T>
+// Store a wave's accumulator tile (32 tokens x NT*32 channels) to `gbase` = address of the tile's first token
+// (plus a channel offset when the tile is a column slice); ROW_CH = channels of a full row in memory (row
+// stride), so a 64-channel half of a 128-channel row can be written on its own.  Rows >= nvalid are not written.
+// Returns the number of wave-level global store instructions issued for a full tile.
+template <int NT, typename T, int ROW_CH = NT * 32>
 LFT_DEV int store_tile(T* __restrict__ gbase, int nvalid, int lane, const f32x16 (&a)[NT], char* scr) {
     using IO = TileIO<NT, T>;
+    constexpr int STRIDE = ROW_CH * (int)sizeof(T);
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -373,19 +402,24 @@ LFT_DEV int store_tile(T* __restrict__ gbase, int nvalid, int lane, const f32x16
                                f32x4{a[nt][4 * g], a[nt][4 * g + 1], a[nt][4 * g + 2], a[nt][4 * g + 3]}, T());
         }
         wave_lds_fence();
-        char* g0 = reinterpret_cast<char*>(gbase) + (size_t)pass * 16 * IO::ROW_BYTES;
+        char* g0 = reinterpret_cast<char*>(gbase) + (size_t)pass * 16 * STRIDE;
+        raw16 v[16 * IO::P16 / 64];
+#pragma unroll
+        for (int i = 0; i < 16 * IO::P16 / 64; ++i) {                     // all LDS reads first, then all stores
+            const int idx = i * 64 + lane;
+            v[i] = load_raw16(scr + (idx / IO::P16) * IO::ROWB + (idx % IO::P16) * 16);
+        }
 #pragma unroll
         for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
             const int idx = i * 64 + lane, row = idx / IO::P16, pc = idx % IO::P16;
-            const raw16 v = load_raw16(scr + row * IO::ROWB + pc * 16);
 #ifndef LFT_EXP_NO_TILE_STORES           // experiment build only (tools/ab_build.py): results are wrong on purpose
-            if (pass * 16 + row < nvalid) store_raw16(g0 + (size_t)idx * 16, v);
+            if (pass * 16 + row < nvalid) store_raw16(g0 + (size_t)row * STRIDE + pc * 16, v[i]);
 #else
-            asm volatile("" :: "v"(v));
+            asm volatile("" :: "v"(v[i]));
 #endif
         }
     }
-    return 2 * (16 * IO::P16 / 64);        // wave-level global store instructions issued when the tile is full
+    return 2 * (16 * IO::P16 / 64);
 }
 
 // Load a wave's tile into the accumulator layout; rows >= nvalid read as zero.  `gbase` must be readable for

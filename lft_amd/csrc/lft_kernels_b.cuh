@@ -10,14 +10,14 @@
 //   n   = LN(tok + PEtok[p])                                 (PEtok = same embedding of the position image, cached)
 //   Q = n Wq^T (pre-scaled by 1/4 * log2 e), K = n Wk^T, V = tok Wv^T
 // Stream: conv[36 x 4] Wv[4x8] Wq[4x8] Wk[4x8]  (240 fragments).
-// PE_ONLY: embed the position image itself and write fp32 tokens (pack-time precompute).
+// PE_ONLY: embed the position image itself and write the tokens (pack-time precompute).
 // ------------------------------------------------------------------------------------------
 constexpr int kSpaChunk = 16;   // fragments per ring chunk: one conv tap (4 k-steps x 4 row tiles), half an in_proj matrix
 template <typename T, bool PE_ONLY>
 __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
-                                              const float* __restrict__ ln, const float* __restrict__ petok,
+                                              const float* __restrict__ ln, const T* __restrict__ petok,
                                               T* __restrict__ TOK, T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vv,
-                                              float* __restrict__ pe_out, int nimg, int h, int w) {
+                                              T* __restrict__ pe_out, int nimg, int h, int w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5, wave = threadIdx.x >> 6;
     const int hw = h * w, tpi = (hw + 127) >> 7;
@@ -26,8 +26,8 @@ __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const 
     const bool ok = p < hw;
     const int pc = min(p, hw - 1);
     LFT_STAMP(0);
-    f32x16 n[4];
-    if (!PE_ONLY) load_acc<4, float>(petok + (size_t)pc * 128, ok, hh, n);   // early: latency hides under the conv
+    typename RawPiece<T>::type pe_raw[16];                                    // position tokens of this lane's token, kept packed
+    if (!PE_ONLY) load_acc_raw<4, T>(petok + (size_t)pc * 128, hh, pe_raw);    // early: latency hides under the conv
     char* lds_in = smem + WRing<T, kSpaChunk>::LDS_BYTES;
     float* lds_ln = reinterpret_cast<float*>(lds_in + ConvIn<T>::bytes(w));
     if (!PE_ONLY) stage_params(ln, lds_ln, 256);                      // norm.{weight,bias}; published by the staging barrier
@@ -40,40 +40,50 @@ __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const 
     conv3x3_tile<4, T>(lds_in, tl, p / w, p % w, ok, h, w, hh, ring, t);
     LFT_STAMP(2);
     if (PE_ONLY) {
-        store_acc<4, float>(pe_out + (size_t)pc * 128, ok, hh, t);
+        store_acc<4, T>(pe_out + (size_t)pc * 128, ok, hh, t);
         return;
     }
     // Tile I/O scratch aliases the (now dead) conv input tile: every wave must be done reading it first.
     __syncthreads();
+    LFT_STAMP(3);
     const int t0 = p0 + wave * 32, nvalid = max(0, min(32, hw - t0));
     const size_t tile_off = ((size_t)im * hw + min(t0, hw - 1)) * 128;
     char* scr = lds_in + wave * TileIO<4, T>::BYTES;
     ring.note_vm(store_tile<4, T>(TOK + tile_off, nvalid, lane, t, scr));
-    Frag<T> nf[8];
-    {   // V = tok Wv^T first (raw tokens, reference LFT.py:185), so that tok can then be normalised in place
-        acc_frags<4, T>(t, nf);
-        f32x16 a[4];
-        zero_acc<4>(a);
-        linear_ring<4, 8, T>(ring, nf, a);
-        LFT_STAMP(3);
-        ring.note_vm(store_tile<4, T>(Vv + tile_off, nvalid, lane, a, scr));
-    }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) t[nt] += n[nt];
-    layernorm_acc<4>(t, lds_ln, lds_ln + 128, hh);
-    acc_frags<4, T>(t, nf);
     LFT_STAMP(4);
-    {
-        f32x16 a[4];
-        zero_acc<4>(a);
-        linear_ring<4, 8, T>(ring, nf, a);
-        ring.note_vm(store_tile<4, T>(Q + tile_off, nvalid, lane, a, scr));
-        zero_acc<4>(a);
-        linear_ring<4, 8, T>(ring, nf, a);
-        LFT_STAMP(5);
-        store_tile<4, T>(K + tile_off, nvalid, lane, a, scr);
+    Frag<T> nf[8];
+    // Each projection is produced and stored in two 64-channel halves: 32 accumulator registers instead of 64
+    // keep the kernel inside 256 VGPRs (2 waves/SIMD) without scratch spills -- a spill reload forces
+    // s_waitcnt vmcnt(0), which drains the weight DMA and every output store in flight.
+    acc_frags<4, T>(t, nf);                    // V = tok Wv^T first (raw tokens, reference LFT.py:185); tok is then normalised in place
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x16 a[2];
+        zero_acc<2>(a);
+        linear_ring<2, 8, T>(ring, nf, a);
+        ring.note_vm(store_tile<2, T, 128>(Vv + tile_off + 64 * half, nvalid, lane, a, scr));
     }
     LFT_STAMP(6);
+    add_acc_raw<4, T>(t, pe_raw, ok);
+    layernorm_acc<4>(t, lds_ln, lds_ln + 128, hh);
+    acc_frags<4, T>(t, nf);
+    LFT_STAMP(7);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x16 a[2];
+        zero_acc<2>(a);
+        linear_ring<2, 8, T>(ring, nf, a);
+        ring.note_vm(store_tile<2, T, 128>(Q + tile_off + 64 * half, nvalid, lane, a, scr));
+    }
+    LFT_STAMP(9);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x16 a[2];
+        zero_acc<2>(a);
+        linear_ring<2, 8, T>(ring, nf, a);
+        ring.note_vm(store_tile<2, T, 128>(K + tile_off + 64 * half, nvalid, lane, a, scr));
+    }
+    LFT_STAMP(11);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -309,7 +319,6 @@ __global__ __launch_bounds__(256, 2) void k_spa2(const T* __restrict__ TOK, cons
     const int nvalid = (int)max(0LL, min(32LL, ntok - t0));
     const long long tb = min(t0, ntok - 1);
     char* scr = smem + WRing<T, kSpaChunk>::LDS_BYTES + 1024 + wave * TileIO<4, T>::BYTES;   // wave-private tile I/O scratch
-    LFT_STAMP(8);
     f32x16 t[4], n[4];
     load_tile<4, T>(TOK + tb * 128, nvalid, lane, t, scr);
     Frag<T> f[8];
@@ -320,14 +329,11 @@ __global__ __launch_bounds__(256, 2) void k_spa2(const T* __restrict__ TOK, cons
     stage_params(ln + 256, lds_ln, 256);                              // feed_forward.0.{weight,bias}; published by the first ring barrier
     WRing<T, kSpaChunk> ring;
     ring.init(ws, smem, 176);
-    LFT_STAMP(9);
     linear_ring<4, 8, T>(ring, f, t);
-    LFT_STAMP(10);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] = t[nt];
     layernorm_acc<4>(n, lds_ln, lds_ln + 128, hh);
     acc_frags<4, T>(n, f);
-    LFT_STAMP(11);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         f32x16 hid[2];
@@ -341,18 +347,15 @@ __global__ __launch_bounds__(256, 2) void k_spa2(const T* __restrict__ TOK, cons
         acc_frags<2, T>(hid, hf);
         linear_ring<4, 4, T>(ring, hf, t);
     }
-    LFT_STAMP(12);
     acc_frags<4, T>(t, f);
     f32x16 y[2];
     zero_acc<2>(y);
     linear_ring<2, 8, T>(ring, f, y);
-    LFT_STAMP(13);
     if (SKIP) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) y[nt] += sk[nt];
     }
     store_tile<2, T>(Y + tb * 64, nvalid, lane, y, scr);
-    LFT_STAMP(14);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -17,5 +17,5 @@ for line in out.splitlines():
 print(f"{'kernel':58s} VGPR AGPR spill scratch occ")
 for k, r in rows.items():
     if "k_" not in k: continue
-    name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", k], capture_output=True, text=True).stdout.strip()[:56]
+    name = k[:56]
     print(f"{name:58s} {r.get('VGPRs',0):4d} {r.get('AGPRs',0):4d} {r.get('VGPRs Spill',0):5d} {r.get('ScratchSize [bytes/lane]',0):7d} {r.get('Occupancy [waves/SIMD]',0):3d}")

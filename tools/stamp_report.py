@@ -34,5 +34,6 @@ def report(title, st, names):
     for i, nm in enumerate(names):
         print(f"  {nm:40s} mean {d[:, i].mean():9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}")
     print(f"  total {np.mean(st[:, -1] - st[:, 0]):.0f}")
-report("k_spa1", allst[:, 0:7], ["petok loads + ring init + stage input", "conv 64->128 (144 MFMA, 9 chunks)", "store tok, +PE, LN, frags", "Q, K (64 MFMA) + stores", "V frags + V (32 MFMA)", "store V"])
-report("k_spa2", allst[:, 8:15], ["loads issued->ring init", "wait loads + Wo (32 MFMA)", "LN + frags", "FFN (128 MFMA)", "Wl (16 MFMA)", "stores"])
+report("k_spa1", allst[:, [0, 1, 2, 3, 4, 6, 7, 9, 11]], ["petok loads, ring init, stage input", "conv 64->128 (144 MFMA, 9 chunks)", "__syncthreads",
+                                   "store TOK tile", "V (32 MFMA) + 2 half-tile stores", "+PE, LN, frags", "Q (32 MFMA) + 2 half-tile stores",
+                                   "K (32 MFMA) + 2 half-tile stores"])
