@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-A, S, H, W = 5, 4, 32, 32          # BASELINE.json metric: 5x5 angRes, 32x32 LR, 4x SR
+A, S, H, W = 5, 4, 32, 32          # BASELINE.json metric: 5x5 angRes, 32x32 LR, 4x SR (overridable for the other configs)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 
 
@@ -110,9 +110,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4, help="LF patches per GPU per step (BASELINE configs[1]: 4)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--ang", type=int, default=5, help="angular resolution (default: the BASELINE metric's 5)")
+    ap.add_argument("--lr", type=int, default=32, help="LR view size (default 32)")
+    ap.add_argument("--scale", type=int, default=4, choices=[2, 4])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    global A, S, H, W
+    A, S, H, W = args.ang, args.scale, args.lr, args.lr
 
     from lft_amd import dp
     rank, local, world = dp.env_world()
@@ -169,14 +174,14 @@ def main():
         peak = PEAK_TFLOPS[args.precision]
         flops_patch = sum(fpt[k] * (V * H * W) * c for k, (_, c) in kb.items() if k != "k_assemble") + fpt["k_assemble"] * (V * H * W)
         result = {
-            "metric": "LF patches/sec (5x5 angRes, 32x32 LR, 4xSR)",
+            "metric": f"LF patches/sec ({A}x{A} angRes, {H}x{W} LR, {S}xSR)",
             "value": world * args.batch * args.steps / dt,
             "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"LFT 5x5 angRes 4xSR inference, batch={args.batch} per GPU, 32x32 LR patches",
+            "config": {"workload": f"LFT {A}x{A} angRes {S}xSR inference, batch={args.batch} per GPU, {H}x{W} LR patches",
                        "global_batch": world * args.batch, "parallelism": f"dp{world} (independent shards)",
                        "algorithmic_gflop_per_patch": flops_patch / 1e9},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -17,7 +17,7 @@
  *  - prec selects the MFMA operand type: LFT_PREC_F32 = exact fp32 (v_mfma_f32_32x32x2_f32),
  *    LFT_PREC_BF16 = bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16).  Activations between
  *    kernels are stored in the same type (float or __bf16, channels-last [B, A*A, h, w, C]).
- *  - Shapes: A = angRes (A*A <= 32 in this version), h x w = LR view size, s = scale factor (2 or 4),
+ *  - Shapes: A = angRes (A*A <= 128 views; 5x5 and 9x9 are the tested ones), h x w = LR view size, s = scale factor (2 or 4),
  *    channels fixed to 64 (reference option.py --channels default, LFT.py:11).
  */
 #ifndef LFT_HIP_H

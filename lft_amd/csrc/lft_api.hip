@@ -62,7 +62,7 @@ int make_dims(int B, int A, int h, int w, int s, int prec, Dims* d) {
     if (prec != LFT_PREC_F32 && prec != LFT_PREC_BF16) return fail(LFT_ERR_ARG, "prec must be LFT_PREC_F32 or LFT_PREC_BF16, got %d", prec);
     if (B < 1 || A < 1 || h < 1 || w < 1) return fail(LFT_ERR_SHAPE, "B, A, h, w must be positive (B=%d A=%d h=%d w=%d)", B, A, h, w);
     if (s != 2 && s != 4) return fail(LFT_ERR_SHAPE, "scale factor must be 2 or 4, got %d", s);
-    if (A * A > 32) return fail(LFT_ERR_UNSUPPORTED, "angRes %d (A*A=%d views > 32) is not implemented in this build", A, A * A);
+    if (A * A > 128) return fail(LFT_ERR_UNSUPPORTED, "angRes %d (A*A=%d views > 128) is not implemented in this build", A, A * A);
     if ((long long)B * A * A * h * w > (1LL << 27)) return fail(LFT_ERR_SHAPE, "too many tokens");
     d->B = B; d->A = A; d->V = A * A; d->h = h; d->w = w; d->hw = h * w; d->s = s;
     d->gp = (s + 2) * (s + 2); d->gt = (d->gp + 31) / 32; d->nchunk = 2 * s * s;
@@ -266,8 +266,25 @@ int init_features(const void* packed, const PackedLayout& L, const float* lr, T*
     LFT_LAUNCH_OK("k_conv64");
     return 0;
 }
+template <typename T, int CT>
+int ang_multi(const void* packed, const PackedLayout& L, int l, const T* in, T* out, const Dims& d, hipStream_t st) {
+    constexpr bool WLDS = sizeof(T) == 2;                                   // fp32 weights (128 KiB) stay in L2
+    constexpr size_t FB = 1024 * FragInfo<T>::PIECES;
+    const size_t lds = (WLDS ? 64 * FB : 0) + 1024 + (size_t)CT * 8 * FB;
+    const int npix = d.B * d.hw;
+    int rc;
+    if ((rc = allow_lds(k_ang_multi<T, CT, WLDS>, lds, "k_ang_multi"))) return rc;
+    const unsigned grid = std::min<unsigned>((unsigned)npix, 256u * (unsigned)std::max<size_t>(1, kMaxLds / lds));
+    k_ang_multi<T, CT, WLDS><<<grid, 64 * CT, lds, st>>>(in, out, at<T>(packed, L.s_ang[l]), at<float>(packed, L.ln_ang[l]),
+                                                         at<float>(packed, L.ang_pe), d.V, d.hw, npix);
+    LFT_LAUNCH_OK("k_ang");
+    return 0;
+}
 template <typename T>
 int ang_block(const void* packed, const PackedLayout& L, int l, const T* in, T* out, const Dims& d, hipStream_t st) {
+    if (d.V > 96) return ang_multi<T, 4>(packed, L, l, in, out, d, st);
+    if (d.V > 64) return ang_multi<T, 3>(packed, L, l, in, out, d, st);      // 9x9 = 81 views
+    if (d.V > 32) return ang_multi<T, 2>(packed, L, l, in, out, d, st);
     const int npix = d.B * d.hw;
     const size_t lds = lds_ang<T>();
     int rc;

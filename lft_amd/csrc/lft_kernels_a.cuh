@@ -320,3 +320,147 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
         store_acc<2, T>(Y + off, ok, hh, x);
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// Angular block for more than 32 views (e.g. 9x9 = 81 views, BASELINE configs[4]).  A workgroup of CT waves
+// owns one spatial position; wave c holds views 32c .. 32c+31 on its MFMA columns and does everything that is
+// per-token (LN, projections, out_proj, FFN) exactly as k_ang.  For the attention each wave publishes its K and V
+// operand fragments (8 per wave) in LDS; after a barrier every wave runs its 32 queries against all CT key tiles:
+// per head CT score tiles (softmax over up to 32*CT keys: registers + one lane^32 exchange) and 2*CT P.V MFMAs.
+// WLDS: weights LDS-resident (bf16); the fp32 parity build reads them from L2 (128 KiB would not leave room).
+// ------------------------------------------------------------------------------------------
+template <typename T, int CT, bool WLDS>
+__global__ __launch_bounds__(64 * CT) void k_ang_multi(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ ws,
+                                                       const float* __restrict__ ln, const float* __restrict__ pe,
+                                                       int V, int hw, int npix) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int FB = 1024 * FragInfo<T>::PIECES;
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* lds_w = smem;                                            // 64 weight fragments when WLDS
+    float* lds_ln = reinterpret_cast<float*>(smem + (WLDS ? 64 * FB : 0));
+    char* lds_kv = reinterpret_cast<char*>(lds_ln) + 1024;         // [CT][8] fragments: K (nt, s) then V (nt, s)
+    if (WLDS) {
+        const char* g = reinterpret_cast<const char*>(ws);
+        for (int piece = wave; piece < 64 * FragInfo<T>::PIECES; piece += CT) glds_piece(g + piece * 1024, lds_w + piece * 1024, lane);
+    }
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x * 4;
+        store_raw16(reinterpret_cast<char*>(lds_ln + i), load_raw16(reinterpret_cast<const char*>(ln + i)));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto wfrag = [&](int f) -> Frag<T> {
+        if (WLDS) return frag_from_pieces(lds_w + f * FB, lane, T());
+        return load_wfrag(ws, f, lane);
+    };
+    const int view = wave * 32 + r;
+    const bool ok = view < V;
+    const int vc = min(view, V - 1);
+    for (int pix = blockIdx.x; pix < npix; pix += gridDim.x) {
+        asm volatile("" ::: "memory");
+        const int b = pix / hw, p = pix % hw;
+        const size_t off = (((size_t)b * V + vc) * hw + p) * 64;
+        f32x16 x[2], n[2];
+        load_acc<2, T>(X + off, ok, hh, x);
+        load_acc<2, float>(pe + (size_t)vc * 64, ok, hh, n);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) n[nt] += x[nt];
+        layernorm_acc<2>(n, lds_ln, lds_ln + 64, hh);
+        Frag<T> nf[4], xf[4];
+        acc_frags<2, T>(n, nf);
+        acc_frags<2, T>(x, xf);
+        f32x16 q[2], o[2];
+        zero_acc<2>(q); zero_acc<2>(o);
+        {
+            f32x16 k[2], v[2];
+            zero_acc<2>(k); zero_acc<2>(v);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    mma(wfrag(nt * 4 + ks), nf[ks], q[nt]);
+                    mma(wfrag(8 + nt * 4 + ks), nf[ks], k[nt]);
+                    mma(xf[ks], wfrag(16 + nt * 4 + ks), v[nt]);      // V[view, ch]: tokens are the A operand
+                }
+            __syncthreads();                                            // previous position's fragments fully consumed
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const Frag<T> kf = acc_to_frag(k[nt], s2, T()), vf = acc_to_frag(v[nt], s2, T());
+                    char* dk = lds_kv + ((wave * 8 + nt * 2 + s2) * FB);
+                    char* dv = lds_kv + ((wave * 8 + 4 + nt * 2 + s2) * FB);
+                    if constexpr (sizeof(T) == 4) {
+                        store_raw16(dk + lane * 16, __builtin_bit_cast(raw16, kf.lo)); store_raw16(dk + 1024 + lane * 16, __builtin_bit_cast(raw16, kf.hi));
+                        store_raw16(dv + lane * 16, __builtin_bit_cast(raw16, vf.lo)); store_raw16(dv + 1024 + lane * 16, __builtin_bit_cast(raw16, vf.hi));
+                    } else {
+                        store_raw16(dk + lane * 16, __builtin_bit_cast(raw16, kf.v));
+                        store_raw16(dv + lane * 16, __builtin_bit_cast(raw16, vf.v));
+                    }
+                }
+            __syncthreads();                                            // all K / V fragments of this position published
+        }
+#pragma unroll
+        for (int hd = 0; hd < 8; ++hd) {
+            const int nt = hd >> 2, s = (hd >> 1) & 1, half = hd & 1;
+            const Frag<T> qf = acc_to_frag(q[nt], s, T());
+            f32x16 S[CT];
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S[j][i] = 0.0f;
+                mma(frag_half(frag_from_pieces(lds_kv + (j * 8 + nt * 2 + s) * FB, lane, T()), half), qf, S[j]);   // S^T[kv, q]
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (32 * j + acc_row(i, hh) >= V) S[j][i] = -INFINITY;
+                    m = fmaxf(m, S[j][i]);
+                }
+            }
+            m = xhalf_max(m);
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { S[j][i] = exp2f(S[j][i] - m); sum += S[j][i]; }
+            const float inv = 1.0f / xhalf_sum(sum);
+            const bool mine = (r >> 3) == (hd & 3);
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S[j][i] *= inv;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    mma(frag_select<T>(mine, frag_from_pieces(lds_kv + (j * 8 + 4 + nt * 2 + s2) * FB, lane, T())), acc_to_frag(S[j], s2, T()), o[nt]);
+            }
+        }
+        Frag<T> of[4];
+        acc_frags<2, T>(o, of);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) mma(wfrag(24 + nt * 4 + ks), of[ks], x[nt]);         // t = x + O Wo^T
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
+        layernorm_acc<2>(n, lds_ln + 128, lds_ln + 192, hh);
+        acc_frags<2, T>(n, nf);
+        f32x16 hid[4];
+        zero_acc<4>(hid);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) mma(wfrag(32 + nt * 4 + ks), nf[ks], hid[nt]);
+        Frag<T> hf[8];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hid[nt][i] = fmaxf(hid[nt][i], 0.0f);
+        acc_frags<4, T>(hid, hf);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) mma(wfrag(48 + nt * 8 + ks), hf[ks], x[nt]);
+        store_acc<2, T>(Y + off, ok, hh, x);
+    }
+}

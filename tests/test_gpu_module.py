@@ -12,7 +12,7 @@ from lft_amd.params import deterministic_state, synthetic_lr
 from oracle import lft_oracle as O
 
 pytestmark = pytest.mark.gpu
-GOLDEN = ["tiny_a5_s2_b2_6x6", "small_a5_s4_b1_8x8", "rect_a5_s2_b1_8x6", "cfg1_a5_s2_b1_32x32", "cfg2_a5_s4_b1_32x32"]
+GOLDEN = ["tiny_a5_s2_b2_6x6", "small_a5_s4_b1_8x8", "small_a9_s4_b1_8x8", "rect_a5_s2_b1_8x6", "cfg1_a5_s2_b1_32x32", "cfg2_a5_s4_b1_32x32"]
 
 
 def make_net(A, s, wseed, flavor, precision):
@@ -66,7 +66,7 @@ def test_loss_and_errors():
     with pytest.raises(ValueError):
         with torch.no_grad():
             net(torch.zeros(1, 1, 41, 40, device="cuda:0"))   # not divisible by angRes
-    net9 = make_net(9, 2, 1, "default", "fp32")
+    net12 = make_net(12, 2, 1, "default", "fp32")
     with pytest.raises(_lib.LftError):
         with torch.no_grad():
-            net9(torch.zeros(1, 1, 72, 72, device="cuda:0"))  # 81 views: not in this build yet
+            net12(torch.zeros(1, 1, 48, 48, device="cuda:0"))  # 144 views: beyond this build (<= 128)

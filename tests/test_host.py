@@ -68,4 +68,5 @@ def test_size_queries_and_argument_errors():
     with pytest.raises(_lib.LftError, match="prec"):
         _lib.packed_bytes(5, 32, 32, 2, 7)
     with pytest.raises(_lib.LftError, match="not implemented"):
-        _lib.packed_bytes(9, 32, 32, 2, _lib.PREC_F32)
+        _lib.packed_bytes(12, 32, 32, 2, _lib.PREC_F32)
+    assert _lib.packed_bytes(9, 32, 32, 4, _lib.PREC_BF16) > 2_000_000      # 9x9 = 81 views is supported
