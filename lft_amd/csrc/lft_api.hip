@@ -86,8 +86,8 @@ PackedLayout packed_layout(const Dims& d, int prec) {
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     L.conv0_w = take(576 * 4);
     for (int l = 0; l < kLayers; ++l) { L.ln_ang[l] = take(256 * 4); L.ln_spa[l] = take(512 * 4); }
-    L.ang_pe = take((size_t)d.V * 64 * 4);
-    for (int l = 0; l < kLayers; ++l) L.petok[l] = take((size_t)d.hw * 128 * esz);
+    L.ang_pe = take((size_t)((d.V + 31) / 32) * 2048 * 4);                       // lane-major, per 32-view tile
+    for (int l = 0; l < kLayers; ++l) L.petok[l] = take((size_t)((d.hw + 127) / 128) * 4 * 4096 * esz);   // lane-major, per 32-token tile
     L.spa_pe_img = take((size_t)d.hw * 64 * esz);
     for (int i = 0; i < 3; ++i) L.s_conv[i] = take(kFragsConv * fragb);
     for (int l = 0; l < kLayers; ++l) {
@@ -124,7 +124,7 @@ template <typename T> size_t lds_spa1(int w) { return WRing<T, kSpaChunk>::LDS_B
 template <typename T> size_t lds_ring() { return WRing<T, kSpaChunk>::LDS_BYTES + kLdsParams; }
 template <typename T> size_t lds_spa2() { return WRing<T, kSpaChunk>::LDS_BYTES + kLdsParams + 4 * TileIO<4, T>::BYTES; }
 template <typename T> size_t lds_up() { return WRing<T, kSpaChunk>::LDS_BYTES + 4 * TileIO<2, T>::BYTES; }
-template <typename T> size_t lds_ang() { return (size_t)kFragsAng * 1024 * FragInfo<T>::PIECES + kLdsParams; }
+template <typename T> size_t lds_ang() { return (size_t)kFragsAng * 1024 * FragInfo<T>::PIECES + kLdsParams + 4 * TileIO<2, T>::BYTES; }
 constexpr size_t kMaxLds = 160 * 1024;
 template <typename K> int allow_lds(K kernel, size_t bytes, const char* name) {
     if (bytes > kMaxLds) return fail(LFT_ERR_SHAPE, "%s needs %zu B of LDS (> 160 KiB): view width too large for this build", name, bytes);
@@ -181,7 +181,7 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
         conv_ops(ops, P[1 + i], 64);
         if ((rc = run_pack<T>(ops, at<T>(packed, L.s_conv[i]), kFragsConv, st))) return rc;
     }
-    k_pe_tables<T><<<blocks_for((long long)std::max(d.V, d.hw) * 64, 256), 256, 0, st>>>(
+    k_pe_tables<T><<<blocks_for(std::max<long long>((long long)((d.V + 31) / 32) * 2048, (long long)d.hw * 64), 256), 256, 0, st>>>(
         at<float>(packed, L.ang_pe), at<T>(packed, L.spa_pe_img), d.V, d.h, d.w);
     LFT_LAUNCH_OK("k_pe_tables");
     for (int l = 0; l < kLayers; ++l) {

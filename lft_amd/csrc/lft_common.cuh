@@ -331,6 +331,28 @@ LFT_DEV void add_acc_raw(f32x16 (&a)[NT], const typename RawPiece<T>::type (&p)[
             for (int j = 0; j < 4; ++j) a[nt][4 * g + j] += ok ? (float)p[nt * 4 + g][j] : 0.0f;
 }
 
+// "Lane-major" tables: input-independent per-token data that a wave consumes in accumulator layout (position
+// tokens, angular PE) is stored at pack time as [tile of 32 tokens][k = nt*2 + g/2][lane][8 elements], lane (h, r)
+// holding pieces g = 2(k&1)... i.e. exactly the 16 four-channel pieces of its token, so that each of the NT*2
+// wave loads is one fully coalesced 64 x 16 B (bf16) or 64 x 32 B (fp32) block instead of touching 32 cache lines.
+template <int NT, typename T>
+LFT_DEV void store_lane_major(T* __restrict__ tile_base, int lane, const f32x16 (&a)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            store4(tile_base + ((size_t)(nt * 2 + (g >> 1)) * 64 + lane) * 8 + (g & 1) * 4,
+                   f32x4{a[nt][4 * g], a[nt][4 * g + 1], a[nt][4 * g + 2], a[nt][4 * g + 3]});
+}
+template <int NT, typename T>
+LFT_DEV void load_lane_major_raw(const T* __restrict__ tile_base, int lane, typename RawPiece<T>::type (&p)[NT * 4]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            p[nt * 4 + g] = *reinterpret_cast<const typename RawPiece<T>::type*>(tile_base + ((size_t)(nt * 2 + (g >> 1)) * 64 + lane) * 8 + (g & 1) * 4);
+}
+
 template <int NT, typename T>
 LFT_DEV void store_acc(T* __restrict__ row, bool ok, int h, const f32x16 (&a)[NT]) {
     if (!ok) return;
@@ -386,9 +408,9 @@ LFT_DEV f32x4 lds_load4(const char* p, bf16_t) {
 // stride), so a 64-channel half of a 128-channel row can be written on its own.  Rows >= nvalid are not written.
 // Returns the number of wave-level global store instructions issued for a full tile.
 template <int NT, typename T, int ROW_CH = NT * 32>
-LFT_DEV int store_tile(T* __restrict__ gbase, int nvalid, int lane, const f32x16 (&a)[NT], char* scr) {
+LFT_DEV int store_tile(T* __restrict__ gbase, int nvalid, int lane, const f32x16 (&a)[NT], char* scr, size_t row_stride_bytes = 0) {
     using IO = TileIO<NT, T>;
-    constexpr int STRIDE = ROW_CH * (int)sizeof(T);
+    const size_t STRIDE = row_stride_bytes ? row_stride_bytes : (size_t)ROW_CH * sizeof(T);
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -425,18 +447,19 @@ LFT_DEV int store_tile(T* __restrict__ gbase, int nvalid, int lane, const f32x16
 // Load a wave's tile into the accumulator layout; rows >= nvalid read as zero.  `gbase` must be readable for
 // max(nvalid,1) rows; rows beyond are not touched.
 template <int NT, typename T>
-LFT_DEV void load_tile(const T* __restrict__ gbase, int nvalid, int lane, f32x16 (&a)[NT], char* scr) {
+LFT_DEV void load_tile(const T* __restrict__ gbase, int nvalid, int lane, f32x16 (&a)[NT], char* scr,
+                       size_t row_stride_bytes = TileIO<NT, T>::ROW_BYTES) {
     using IO = TileIO<NT, T>;
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        const char* g0 = reinterpret_cast<const char*>(gbase) + (size_t)pass * 16 * IO::ROW_BYTES;
+        const char* g0 = reinterpret_cast<const char*>(gbase) + (size_t)pass * 16 * row_stride_bytes;
         raw16 v[16 * IO::P16 / 64];
 #pragma unroll
         for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
-            const int idx = i * 64 + lane, row = idx / IO::P16;
+            const int idx = i * 64 + lane, row = idx / IO::P16, pc = idx % IO::P16;
             const bool in = pass * 16 + row < nvalid;
-            const raw16 t = load_raw16(in ? g0 + (size_t)idx * 16 : reinterpret_cast<const char*>(gbase));
+            const raw16 t = load_raw16(in ? g0 + (size_t)row * row_stride_bytes + pc * 16 : reinterpret_cast<const char*>(gbase));
             v[i] = in ? t : raw16{0u, 0u, 0u, 0u};
         }
         wave_lds_fence();                                              // previous pass fully consumed
@@ -528,11 +551,16 @@ LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* gamma, const float* bet
             for (int j = 0; j < 4; ++j) a[nt][4 * g + j] = (a[nt][4 * g + j] - mean) * rstd * gm[j] + bt[j];
         }
 }
-// copy n floats (n % 4 == 0, n <= 1024) of LayerNorm parameters global -> LDS; caller synchronises (the first
-// ring barrier, or an explicit one, comes before any use).
-LFT_DEV void stage_params(const float* __restrict__ src, float* lds_dst, int n) {
+// LayerNorm parameters global -> LDS in two halves: the load is issued early with everything else, the LDS
+// store only after the kernel's one big vmcnt wait (a load -> ds_write pair in the prologue costs a full memory
+// round trip there, vmcnt being in-order).  n % 4 == 0, n <= 1024.  The caller's barrier publishes the store.
+LFT_DEV raw16 params_load(const float* __restrict__ src, int n) {
+    const int i = min((int)threadIdx.x * 4, n - 4);
+    return load_raw16(reinterpret_cast<const char*>(src + i));
+}
+LFT_DEV void params_store(float* lds_dst, int n, raw16 v) {
     const int i = threadIdx.x * 4;
-    if (i < n) store_raw16(reinterpret_cast<char*>(lds_dst + i), load_raw16(reinterpret_cast<const char*>(src + i)));
+    if (i < n) store_raw16(reinterpret_cast<char*>(lds_dst + i), v);
 }
 
 // all 2*NT k-steps of an accumulator-resident activation as fragments

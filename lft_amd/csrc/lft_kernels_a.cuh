@@ -61,10 +61,17 @@ LFT_DEV float pe_value(int l, int c) {
     const float p = (float)l / g;
     return (c < 32) ? (float)sin((double)p) : (float)cos((double)p);
 }
+// Angular table: lane-major fp32 (see load_lane_major_raw): [view tile][k = 0..3][lane][8].
 template <typename T>
 __global__ void k_pe_tables(float* __restrict__ ang_pe, T* __restrict__ spa_img, int V, int h, int w) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < V * 64) ang_pe[idx] = pe_value(idx >> 6, idx & 63);
+    const int ntile = (V + 31) / 32;
+    if (idx < ntile * 2048) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, k = (idx >> 9) & 3, ct = idx >> 11;
+        const int view = ct * 32 + (lane & 31), nt = k >> 1, g = 2 * (k & 1) + (e >> 2);
+        const int ch = 32 * nt + 8 * g + 4 * (lane >> 5) + (e & 3);
+        ang_pe[idx] = view < V ? pe_value(view, ch) : 0.0f;
+    }
     if (idx < h * w * 64) {
         const int p = idx >> 6, c = idx & 63;
         spa_img[idx] = (T)((pe_value(p / w, c) + pe_value(p % w, c)) / 2.0f);
@@ -115,57 +122,66 @@ __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, con
 // ------------------------------------------------------------------------------------------
 // Per-view 3x3 convolution, 64 -> 32*NT channels, as an implicit GEMM.  A workgroup owns 128
 // consecutive tokens of one view image (4 waves x 32 tokens); K = 9 taps x 64 channels = 36 k-steps.
-//  * input: the 128 tokens plus a halo of w+1 tokens on either side are staged ONCE into LDS (each
-//    token row is re-read by up to 9 taps); rows are padded by 16 B so the per-lane 16-byte reads of
-//    32 different token rows spread over all 64 banks.  Tokens outside the image are staged as zeros;
-//    the left/right image border is handled by the lane predicate (per-view zero padding,
-//    reference LFT.py:24,27,167).
+//  * input: the 128 tokens plus a halo of w+1 tokens on either side are brought into LDS ONCE (each token row is
+//    re-read by up to 9 taps) by LDS-DMA: no registers, no round trip before the data is needed, and it
+//    shares one wait with the first weight chunks.  LDS-DMA writes lane-linear 1 KiB pieces, so rows are
+//    unpadded (128 B bf16 / 256 B fp32) and bank conflicts are removed by an XOR swizzle applied on the
+//    per-lane SOURCE address and again on the read (16-byte piece c of slot s lives at piece c ^ f(s)):
+//    conflict-free for every tile alignment (checked exhaustively offline; unswizzled it is 8- / 16-way).
+//    Tokens outside the image are fetched from a clamped address and never used: the lane predicate zeroes
+//    them, as it does at the left/right image border (per-view zero padding, reference LFT.py:24,27,167).
 //  * weights: the fragment stream ((tap*4 + ks) * NT + nt) arrives through the workgroup's LDS ring.
 // ------------------------------------------------------------------------------------------
 template <typename T> struct ConvIn {
-    static constexpr int ROW_BYTES = 64 * (int)sizeof(T) + 16;
-    static constexpr int PPR = 64 * (int)sizeof(T) / 16;            // 16-byte pieces per token row
+    static constexpr int ROW_BYTES = 64 * (int)sizeof(T);
+    static constexpr int PPR = ROW_BYTES / 16;                       // 16-byte pieces per token row (8 / 16)
+    static constexpr int SLOTS_PER_DMA = 1024 / ROW_BYTES;           // token rows per 1 KiB LDS-DMA piece (8 / 4)
     static __host__ __device__ int slots(int w) { return 130 + 2 * w; }
-    static __host__ __device__ int bytes(int w) { return slots(w) * ROW_BYTES; }
+    static __host__ __device__ int dma_pieces(int w) { return (slots(w) + SLOTS_PER_DMA - 1) / SLOTS_PER_DMA; }
+    static __host__ __device__ int bytes(int w) { return dma_pieces(w) * 1024; }
+    static __device__ __forceinline__ int swz(int slot) { return sizeof(T) == 2 ? ((slot >> 1) & 7) : (slot & 15); }
 };
 
+// Issues the DMA only; the caller waits (vmcnt) and publishes (barrier) before the first read.
 template <typename T>
 LFT_DEV void stage_conv_input(const T* __restrict__ img, int p0, int hw, int w, char* lds_in) {
-    const int n = ConvIn<T>::slots(w) * ConvIn<T>::PPR;
-    constexpr int BATCH = 4;                  // loads in flight per thread: issue all, then store all (no per-pass round trip)
-    for (int base = threadIdx.x; base < n; base += 256 * BATCH) {
-        raw16 v[BATCH];
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            const int idx = min(base + 256 * u, n - 1);
-            const int slot = idx / ConvIn<T>::PPR, piece = idx % ConvIn<T>::PPR;
-            const int q = p0 - w - 1 + slot;
-            const bool in = q >= 0 && q < hw;
-            const raw16 t = load_raw16(reinterpret_cast<const char*>(img) + ((size_t)(in ? q : 0) * 64 * sizeof(T) + piece * 16));
-            v[u] = in ? t : raw16{0u, 0u, 0u, 0u};
-        }
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            const int idx = base + 256 * u;
-            if (idx < n) store_raw16(lds_in + (idx / ConvIn<T>::PPR) * ConvIn<T>::ROW_BYTES + (idx % ConvIn<T>::PPR) * 16, v[u]);
-        }
+    using CI = ConvIn<T>;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int npieces = CI::dma_pieces(w);
+    for (int piece = wave; piece < npieces; piece += 4) {
+        const int slot = piece * CI::SLOTS_PER_DMA + lane / CI::PPR, cpos = lane % CI::PPR;
+        const int q = min(max(p0 - w - 1 + slot, 0), hw - 1);                       // clamped: out-of-image rows are masked at use
+        const char* src = reinterpret_cast<const char*>(img) + ((size_t)q * CI::ROW_BYTES + ((cpos ^ CI::swz(slot)) * 16));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_in + piece * 1024), 16, 0, 0);
     }
-    __syncthreads();   // publish the tile: conv3x3_tile reads a B fragment BEFORE its first ring.next() barrier
 }
+LFT_DEV void wait_staged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // own DMA pieces and early loads landed
 
 // tl = token index inside the workgroup tile (0..127); (y, x) its image coordinates.
 template <int NT, typename T, int CH>
 LFT_DEV void conv3x3_tile(const char* lds_in, int tl, int y, int x, bool ok, int h, int w, int hh,
                           WRing<T, CH>& ring, f32x16 (&acc)[NT]) {
+    using CI = ConvIn<T>;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         const int yy = y + dy, xx = x + dx;
         const bool inb = ok && yy >= 0 && yy < h && xx >= 0 && xx < w;
-        const char* row = lds_in + (tl + w + 1 + dy * w + dx) * ConvIn<T>::ROW_BYTES + 8 * hh * (int)sizeof(T);
+        const int slot = tl + w + 1 + dy * w + dx;
+        const char* row = lds_in + slot * CI::ROW_BYTES;
+        const int sw = CI::swz(slot);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const Frag<T> b = lds_row8(row + 16 * ks * (int)sizeof(T), inb, T());
+            Frag<T> b;
+            if constexpr (sizeof(T) == 2) {
+                b.v = __builtin_bit_cast(bf16x8, load_raw16(row + (((2 * ks + hh) ^ sw) * 16)));
+            } else {
+                b.lo = __builtin_bit_cast(f32x4, load_raw16(row + (((4 * ks + 2 * hh) ^ sw) * 16)));
+                b.hi = __builtin_bit_cast(f32x4, load_raw16(row + (((4 * ks + 2 * hh + 1) ^ sw) * 16)));
+            }
+            if (!inb) b = frag_zero(T());
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) mma(ring.next(), b, acc[nt]);
         }
@@ -192,6 +208,8 @@ __global__ __launch_bounds__(256) void k_conv64(const T* __restrict__ in, T* __r
     WRing<T, kConv64Chunk> ring;
     ring.init(wstream, smem, 72);
     stage_conv_input<T>(in + (size_t)im * hw * 64, p0, hw, w, lds_in);
+    wait_staged();
+    __syncthreads();                                                                 // ... and everybody else's
     f32x16 acc[2];
     zero_acc<2>(acc);
     conv3x3_tile<2, T>(lds_in, tl, p / w, p % w, ok, h, w, hh, ring, acc);
@@ -246,20 +264,27 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
         }
     }
     float* lds_ln = reinterpret_cast<float*>(smem + 64 * FB);
-    stage_params(ln, lds_ln, 256);
+    const raw16 lnv = params_load(ln, 256);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own LDS-DMA pieces landed, then publish (see WRing::next)
+    params_store(lds_ln, 256, lnv);
     __syncthreads();
     const bool ok = r < V;
+    char* scr = reinterpret_cast<char*>(lds_ln) + 1024 + wave * TileIO<2, T>::BYTES;        // wave-private tile I/O scratch
+    const size_t vstride = (size_t)hw * 64 * sizeof(T);                                   // one view to the next, same position
     for (int pix = blockIdx.x * 4 + wave; pix < npix; pix += gridDim.x * 4) {
         asm volatile("" ::: "memory");    // keep the (loop-invariant) LDS weight reads inside the loop: hoisted, they cost 256+ VGPRs
-        const int b = pix / hw, p = pix % hw, rc = min(r, V - 1);
-        const size_t off = (((size_t)b * V + rc) * hw + p) * 64;
+        const int b = pix / hw, p = pix % hw;
+        const size_t off0 = (((size_t)b * V) * hw + p) * 64;                              // view 0 of this position
 
         f32x16 x[2], n[2];
-        load_acc<2, T>(X + off, ok, hh, x);
-        load_acc<2, float>(pe + (size_t)rc * 64, ok, hh, n);
+        load_tile<2, T>(X + off0, V, lane, x, scr, vstride);                              // rows = views: 8 lanes x 16 B per row
+        {
+            typename RawPiece<float>::type pr[8];
+            load_lane_major_raw<2, float>(pe, lane, pr);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) n[nt] += x[nt];
+            for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
+            add_acc_raw<2, float>(n, pr, ok);
+        }
         layernorm_acc<2>(n, lds_ln, lds_ln + 64, hh);
         Frag<T> nf[4], xf[4];
         acc_frags<2, T>(n, nf);
@@ -317,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
             for (int i = 0; i < 16; ++i) hid[nt][i] = fmaxf(hid[nt][i], 0.0f);
         acc_frags<4, T>(hid, hf);
         linear_lds<2, 8, T>(smem, 48, lane, hf, x);
-        store_acc<2, T>(Y + off, ok, hh, x);
+        store_tile<2, T>(Y + off0, V, lane, x, scr, vstride);
     }
 }
 
@@ -363,9 +388,13 @@ __global__ __launch_bounds__(64 * CT) void k_ang_multi(const T* __restrict__ X, 
         const size_t off = (((size_t)b * V + vc) * hw + p) * 64;
         f32x16 x[2], n[2];
         load_acc<2, T>(X + off, ok, hh, x);
-        load_acc<2, float>(pe + (size_t)vc * 64, ok, hh, n);
+        {
+            typename RawPiece<float>::type pr[8];
+            load_lane_major_raw<2, float>(pe + (size_t)wave * 2048, lane, pr);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) n[nt] += x[nt];
+            for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
+            add_acc_raw<2, float>(n, pr, ok);
+        }
         layernorm_acc<2>(n, lds_ln, lds_ln + 64, hh);
         Frag<T> nf[4], xf[4];
         acc_frags<2, T>(n, nf);

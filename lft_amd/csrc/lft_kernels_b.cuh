@@ -27,20 +27,26 @@ __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const 
     const int pc = min(p, hw - 1);
     LFT_STAMP(0);
     typename RawPiece<T>::type pe_raw[16];                                    // position tokens of this lane's token, kept packed
-    if (!PE_ONLY) load_acc_raw<4, T>(petok + (size_t)pc * 128, hh, pe_raw);    // early: latency hides under the conv
+    if (!PE_ONLY) load_lane_major_raw<4, T>(petok + (size_t)((p0 >> 5) + wave) * 4096, lane, pe_raw);   // early, 8 coalesced loads
     char* lds_in = smem + WRing<T, kSpaChunk>::LDS_BYTES;
     float* lds_ln = reinterpret_cast<float*>(lds_in + ConvIn<T>::bytes(w));
-    if (!PE_ONLY) stage_params(ln, lds_ln, 256);                      // norm.{weight,bias}; published by the staging barrier
+    raw16 lnv = raw16{0u, 0u, 0u, 0u};
+    if (!PE_ONLY) lnv = params_load(ln, 256);                         // norm.{weight,bias}; ln is null in the pack-time PE_ONLY launch
     WRing<T, kSpaChunk> ring;
     ring.init(ws, smem, PE_ONLY ? 144 : 240, p0 + 128 <= hw);
     stage_conv_input<T>(X + (size_t)im * hw * 64, p0, hw, w, lds_in);
+    LFT_STAMP(12);
+    wait_staged();
+    LFT_STAMP(13);
+    if (!PE_ONLY) params_store(lds_ln, 256, lnv);
+    __syncthreads();                                                  // input tile, first weight chunks and LN parameters published
     LFT_STAMP(1);
     f32x16 t[4];
     zero_acc<4>(t);
     conv3x3_tile<4, T>(lds_in, tl, p / w, p % w, ok, h, w, hh, ring, t);
     LFT_STAMP(2);
     if (PE_ONLY) {
-        store_acc<4, T>(pe_out + (size_t)pc * 128, ok, hh, t);
+        store_lane_major<4, T>(pe_out + (size_t)((p0 >> 5) + wave) * 4096, lane, t);   // lane-major table, one 32-token tile per wave
         return;
     }
     // Tile I/O scratch aliases the (now dead) conv input tile: every wave must be done reading it first.
@@ -259,6 +265,55 @@ __global__ __launch_bounds__(512) void k_spa_attn_lds(const bf16_t* __restrict__
     const long long img0 = (long long)im * h * w;
     const long long tok = img0 + min(y, h - 1) * w + min(x, w - 1);
     const int y0 = max(0, y - 2), y1 = min(h, y + 3), x0 = max(0, x - 2), x1 = min(min(h, x + 3), w);   // reference LFT.py:155 (sic)
+#ifdef LFT_ATT_FMA
+    // Experiment (tools/ab_build.py fma:-DLFT_ATT_FMA): unpack bf16 by shift / mask and use plain fp32 FMAs.
+    // Measured 102 us vs 64 us for the v_dot2c_f32_bf16 form below: the kernel is VALU-issue-bound, fewer instructions win.
+    float q[16];
+    {
+        bf16x2 qp[8];
+        load_pairs16(Q + tok * 128 + hg * 64 + hl * 16, qp);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { q[2 * c] = (float)qp[c][0]; q[2 * c + 1] = (float)qp[c][1]; }
+    }
+    att_stage(K, smem, img0, ty, tx, hg, h, w);
+    __syncthreads();
+    float s[25];
+    float m = -INFINITY;
+    const char* base = smem + (qrow * kAttHC + qcol) * kAttRow + hl * 32;
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
+        const raw16 k0 = load_raw16(base + ((t / 5) * kAttHC + t % 5) * kAttRow), k1 = load_raw16(base + ((t / 5) * kAttHC + t % 5) * kAttRow + 16);
+        float d = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            d += q[2 * c] * __builtin_bit_cast(float, k0[c] << 16) + q[2 * c + 1] * __builtin_bit_cast(float, k0[c] & 0xffff0000u);
+            d += q[8 + 2 * c] * __builtin_bit_cast(float, k1[c] << 16) + q[8 + 2 * c + 1] * __builtin_bit_cast(float, k1[c] & 0xffff0000u);
+        }
+        s[t] = (ky >= y0 && ky < y1 && kx >= x0 && kx < x1) ? d : -INFINITY;
+        m = fmaxf(m, s[t]);
+    }
+    __syncthreads();                       // everyone is done with K
+    att_stage(Vv, smem, img0, ty, tx, hg, h, w);
+    __syncthreads();
+    float sum = 0.0f, o[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) o[c] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        float pr = (s[t] != -INFINITY) ? exp2f(s[t] - m) : 0.0f;
+        sum += pr;
+        pr = (float)(bf16_t)pr;            // P rounded to bf16, as an MFMA operand would be
+        const raw16 v0 = load_raw16(base + ((t / 5) * kAttHC + t % 5) * kAttRow), v1 = load_raw16(base + ((t / 5) * kAttHC + t % 5) * kAttRow + 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            o[2 * c] += pr * __builtin_bit_cast(float, v0[c] << 16);
+            o[2 * c + 1] += pr * __builtin_bit_cast(float, v0[c] & 0xffff0000u);
+            o[8 + 2 * c] += pr * __builtin_bit_cast(float, v1[c] << 16);
+            o[8 + 2 * c + 1] += pr * __builtin_bit_cast(float, v1[c] & 0xffff0000u);
+        }
+    }
+#else
     bf16x2 q[8], kv[8];
     load_pairs16(Q + tok * 128 + hg * 64 + hl * 16, q);
     att_stage(K, smem, img0, ty, tx, hg, h, w);
@@ -295,6 +350,7 @@ __global__ __launch_bounds__(512) void k_spa_attn_lds(const bf16_t* __restrict__
             o[2 * c + 1] = __builtin_amdgcn_fdot2_f32_bf16(p1, kv[c], o[2 * c + 1], false);
         }
     }
+#endif
     if (!valid) return;
     const float inv = 1.0f / sum;          // empty window (h < w quirk): 0 * inf = NaN as in the reference
 #pragma unroll
@@ -326,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void k_spa2(const T* __restrict__ TOK, cons
     f32x16 sk[2];
     if (SKIP) load_tile<2, T>(skip + tb * 64, nvalid, lane, sk, scr);
     float* lds_ln = reinterpret_cast<float*>(smem + WRing<T, kSpaChunk>::LDS_BYTES);
-    stage_params(ln + 256, lds_ln, 256);                              // feed_forward.0.{weight,bias}; published by the first ring barrier
+    params_store(lds_ln, 256, params_load(ln + 256, 256));            // feed_forward.0.{weight,bias}; the tile loads above were waited for anyway; published by the first ring barrier
     WRing<T, kSpaChunk> ring;
     ring.init(ws, smem, 176);
     linear_ring<4, 8, T>(ring, f, t);

@@ -37,3 +37,9 @@ def report(title, st, names):
 report("k_spa1", allst[:, [0, 1, 2, 3, 4, 6, 7, 9, 11]], ["petok loads, ring init, stage input", "conv 64->128 (144 MFMA, 9 chunks)", "__syncthreads",
                                    "store TOK tile", "V (32 MFMA) + 2 half-tile stores", "+PE, LN, frags", "Q (32 MFMA) + 2 half-tile stores",
                                    "K (32 MFMA) + 2 half-tile stores"])
+
+st = allst
+first, second = st[:512], st[512:800]
+for nm, g in (("first-round WGs (block < 512)", first), ("second-round WGs", second)):
+    print(f"{nm}: issue loads + DMA {np.mean(g[:,12]-g[:,0]):.0f}, wait vmcnt(0) {np.mean(g[:,13]-g[:,12]):.0f}, barrier {np.mean(g[:,1]-g[:,13]):.0f}, "
+          f"conv {np.mean(g[:,2]-g[:,1]):.0f}, rest {np.mean(g[:,11]-g[:,2]):.0f}, total {np.mean(g[:,11]-g[:,0]):.0f}")
