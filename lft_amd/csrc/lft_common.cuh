@@ -520,6 +520,9 @@ LFT_DEV void zero_acc(f32x16 (&a)[NT]) {
         for (int i = 0; i < 16; ++i) a[nt][i] = 0.0f;
 }
 
+// 2^x for softmax arguments (x <= 0): the bare v_exp_f32.  exp2f() wraps it in ldexp / compare / select range
+// handling (4 extra VALU instructions per call); results below 2^-126 flush to 0, which a softmax does not mind.
+LFT_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 LFT_DEV float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 LFT_DEV float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
 

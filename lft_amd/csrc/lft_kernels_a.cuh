@@ -269,6 +269,9 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
     params_store(lds_ln, 256, lnv);
     __syncthreads();
     const bool ok = r < V;
+    f32x16 negmask;                                                                       // 0 for key rows < V, -inf beyond
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negmask[i] = acc_row(i, hh) >= V ? -INFINITY : 0.0f;
     char* scr = reinterpret_cast<char*>(lds_ln) + 1024 + wave * TileIO<2, T>::BYTES;        // wave-private tile I/O scratch
     const size_t vstride = (size_t)hw * 64 * sizeof(T);                                   // one view to the next, same position
     for (int pix = blockIdx.x * 4 + wave; pix < npix; pix += gridDim.x * 4) {
@@ -302,27 +305,23 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
 #pragma unroll
         for (int hd = 0; hd < 8; ++hd) {
             const int nt = hd >> 2, s = (hd >> 1) & 1, half = hd & 1;
-            f32x16 S;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) S[i] = 0.0f;
+            f32x16 S = negmask;                                    // rows of non-existent views start at -inf: no per-head masking
             mma(frag_half(acc_to_frag(k[nt], s, T()), half), acc_to_frag(q[nt], s, T()), S);   // S^T[kv, q]
-            float m = -INFINITY;
+            float m = S[0];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (acc_row(i, hh) >= V) S[i] = -INFINITY;
-                m = fmaxf(m, S[i]);
-            }
+            for (int i = 1; i < 16; ++i) m = fmaxf(m, S[i]);
             m = xhalf_max(m);
             float sum = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { S[i] = exp2f(S[i] - m); sum += S[i]; }
+            for (int i = 0; i < 16; ++i) { S[i] = fast_exp2(S[i] - m); sum += S[i]; }
             const float inv = 1.0f / xhalf_sum(sum);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) S[i] *= inv;
             const bool mine = (r >> 3) == (hd & 3);          // this lane's channel belongs to head hd
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
                 mma(frag_select<T>(mine, acc_to_frag(v[nt], s2, T())), acc_to_frag(S, s2, T()), o[nt]);
+            // normalise afterwards: head hd owns output rows 8*(hd&3)..+7 = registers 4*(hd&3)..+3 of o[nt], written by no other head
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[nt][4 * (hd & 3) + i] *= inv;
         }
 
         Frag<T> of[4];
@@ -439,30 +438,26 @@ __global__ __launch_bounds__(64 * CT) void k_ang_multi(const T* __restrict__ X, 
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) S[j][i] = 0.0f;
+                for (int i = 0; i < 16; ++i) S[j][i] = (32 * j + acc_row(i, hh) >= V) ? -INFINITY : 0.0f;
                 mma(frag_half(frag_from_pieces(lds_kv + (j * 8 + nt * 2 + s) * FB, lane, T()), half), qf, S[j]);   // S^T[kv, q]
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if (32 * j + acc_row(i, hh) >= V) S[j][i] = -INFINITY;
-                    m = fmaxf(m, S[j][i]);
-                }
+                for (int i = 0; i < 16; ++i) m = fmaxf(m, S[j][i]);
             }
             m = xhalf_max(m);
             float sum = 0.0f;
 #pragma unroll
             for (int j = 0; j < CT; ++j)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { S[j][i] = exp2f(S[j][i] - m); sum += S[j][i]; }
+                for (int i = 0; i < 16; ++i) { S[j][i] = fast_exp2(S[j][i] - m); sum += S[j][i]; }
             const float inv = 1.0f / xhalf_sum(sum);
             const bool mine = (r >> 3) == (hd & 3);
 #pragma unroll
-            for (int j = 0; j < CT; ++j) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) S[j][i] *= inv;
+            for (int j = 0; j < CT; ++j)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
                     mma(frag_select<T>(mine, frag_from_pieces(lds_kv + (j * 8 + 4 + nt * 2 + s2) * FB, lane, T())), acc_to_frag(S[j], s2, T()), o[nt]);
-            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[nt][4 * (hd & 3) + i] *= inv;
         }
         Frag<T> of[4];
         acc_frags<2, T>(o, of);

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_spa_attn(const T* __restrict__ Q, const
     for (int t = 0; t < 25; ++t) {
         const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
         if (s[t] != -INFINITY) {
-            const float pr = exp2f(s[t] - m);
+            const float pr = fast_exp2(s[t] - m);
             sum += pr;
             load16<T>(Vv + (img0 + ky * w + kx) * 128 + head * 16, kv);
 #pragma unroll
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_spa_attn<bf16_t>(const bf16_t* __restri
     for (int t = 0; t < 25; ++t) {
         const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
         if (s[t] != -INFINITY) {
-            const float pr = exp2f(s[t] - m);
+            const float pr = fast_exp2(s[t] - m);
             sum += pr;
             const bf16_t pb = (bf16_t)pr;
             const bf16x2 p0 = bf16x2{pb, (bf16_t)0.0f}, p1 = bf16x2{(bf16_t)0.0f, pb};
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512) void k_spa_attn_lds(const bf16_t* __restrict__
     for (int c = 0; c < 16; ++c) o[c] = 0.0f;
 #pragma unroll
     for (int t = 0; t < 25; ++t) {
-        float pr = (s[t] != -INFINITY) ? exp2f(s[t] - m) : 0.0f;
+        float pr = (s[t] != -INFINITY) ? fast_exp2(s[t] - m) : 0.0f;
         sum += pr;
         pr = (float)(bf16_t)pr;            // P rounded to bf16, as an MFMA operand would be
         const raw16 v0 = load_raw16(base + ((t / 5) * kAttHC + t % 5) * kAttRow), v1 = load_raw16(base + ((t / 5) * kAttHC + t % 5) * kAttRow + 16);
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512) void k_spa_attn_lds(const bf16_t* __restrict__
     for (int c = 0; c < 16; ++c) o[c] = 0.0f;
 #pragma unroll
     for (int t = 0; t < 25; ++t) {
-        const float pr = (s[t] != -INFINITY) ? exp2f(s[t] - m) : 0.0f;
+        const float pr = (s[t] != -INFINITY) ? fast_exp2(s[t] - m) : 0.0f;
         sum += pr;
         const bf16_t pb = (bf16_t)pr;
         const bf16x2 p0 = bf16x2{pb, (bf16_t)0.0f}, p1 = bf16x2{(bf16_t)0.0f, pb};
