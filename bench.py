@@ -8,8 +8,9 @@ data-parallel shards (weak scaling, no data-path collective); one process per GP
 torch.distributed.run, barrier + synchronize on both sides of the timed region, max over ranks.
 
 Prints ONE JSON line on rank 0 with the extra objects
-  roofline     : the dominant kernel's algorithmic FLOP/s (HIP events on the launch stream, inside this run)
-                 against the dense bf16 MFMA peak (2.5 PFLOP/s; fp32 path: 157.3 TFLOP/s)
+  roofline     : for the dominant kernel (largest share of GPU time; HIP events on the launch stream, inside this run)
+                 its algorithmic FLOPs and HBM bytes per launch decide the bound -- dense bf16 MFMA peak 2.5 PFLOP/s
+                 (fp32 path 157.3 TFLOP/s) or HBM 8 TB/s -- and `achieved`/`frac` are quoted against that peak
   cpu_baseline : the CPU oracle (a port of the reference's operator sequence, oracle/lft_oracle.py) timed on
                  this node's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -48,6 +49,25 @@ def flops_per_token(s: int, V: int, wbar: float) -> dict:
     }
 
 
+def bytes_per_token(s: int, esz: int) -> dict:
+    """Algorithmic HBM bytes per token and kernel: every activation tensor a kernel must read or write once
+    (esz = bytes per stored activation element; weights and tables are amortised over the batch and ignored)."""
+    C, E, gp = 64, 128, (s + 2) * (s + 2)
+    return {
+        "k_conv0": 4 + C * esz,                       # LR pixel in, 64-channel token out
+        "k_conv64": 2 * C * esz,                      # token in, token out (the residual read of the 3rd conv is ignored)
+        "k_ang": 2 * C * esz,
+        "k_spa1": C * esz + 4 * E * esz,              # x in; tok, Q, K, V out
+        "k_spa_attn": 4 * E * esz,                    # Q, K, V in (halo re-reads are not algorithmic); O out
+        "k_spa2": 2 * E * esz + C * esz,              # tok, O in; x out
+        "k_up": C * esz + gp * 4,                     # x in; (s+2)^2 fp32 footprint out
+        "k_assemble": gp * 4 + 4 + s * s * 4,         # footprint + LR pixel in; s*s HR pixels out
+    }
+
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
 def mean_window(h: int, w: int) -> float:
     cnt = lambda n: sum(min(n, i + 3) - max(0, i - 2) for i in range(n))  # noqa: E731
     return cnt(h) * cnt(w) / (h * w)
@@ -61,7 +81,7 @@ def kernel_breakdown(net, lr, reps: int):
     prec = _PREC[net.precision]
     stream = torch.cuda.current_stream().cuda_stream
     packed = net._ensure_packed(lr.device, H, W, prec, stream)
-    work = net._ensure_work(lr.device, B, H, W, prec)
+    work = net._ensure_work(lr.device, B, H, W, prec, slot="profile")
     out = torch.empty((B, 1, A * H * S, A * W * S), dtype=torch.float32, device=lr.device)
     n_max = 64
     ms = (ctypes.c_float * n_max)()
@@ -113,6 +133,8 @@ def main():
     ap.add_argument("--ang", type=int, default=5, help="angular resolution (default: the BASELINE metric's 5)")
     ap.add_argument("--lr", type=int, default=32, help="LR view size (default 32)")
     ap.add_argument("--scale", type=int, default=4, choices=[2, 4])
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the per-GPU batch is split over (1 = single stream)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host each step instead of replaying a HIP graph")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -134,7 +156,7 @@ def main():
 
     from lft_amd.params import deterministic_state, synthetic_lr
     from model import LFT
-    net = LFT.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=S), precision=args.precision)
+    net = LFT.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=S), precision=args.precision, streams=args.streams)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in deterministic_state(64, S, seed=1).items()})
     net = net.to(dev).eval()
     lr = torch.from_numpy(synthetic_lr(args.batch, A, H, W, seed=rank)).to(dev)   # resident in HBM
@@ -145,13 +167,17 @@ def main():
         torch.cuda.synchronize()
 
     note(f"rank {rank}/{world}: model on {dev}, precision {args.precision}, batch {args.batch}")
+    step = net
+    if not args.no_graph:
+        from lft_amd.module import GraphedForward
+        step = GraphedForward(net, lr)            # one HIP-graph launch per step; lr is the graph's resident input buffer
     with torch.no_grad():
         for _ in range(args.warmup):
-            out = net(lr)
+            out = step(lr)
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = net(lr)
+            out = step(lr)
         sync()
         dt = time.perf_counter() - t0
     assert bool(torch.isfinite(out).all())
@@ -169,10 +195,20 @@ def main():
         note("kernel ms/launch: " + ", ".join(f"{k}={ms:.3f}x{c}" for k, (ms, c) in kb.items()))
         dom = max(kb, key=lambda k: kb[k][0] * kb[k][1])
         dom_ms, dom_cnt = kb[dom]
-        units = args.batch * A * H * S * A * W * S if dom == "k_assemble" else ntok
-        achieved = fpt[dom] * units / (dom_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
-        flops_patch = sum(fpt[k] * (V * H * W) * c for k, (_, c) in kb.items() if k != "k_assemble") + fpt["k_assemble"] * (V * H * W)
+        bpt = bytes_per_token(S, 2 if args.precision == "bf16" else 4)
+
+        def roof(k, ms):
+            """Roofline of one kernel: the larger of (FLOPs / MFMA peak) and (bytes / HBM peak) names the bound."""
+            gflop = fpt[k] * ntok / 1e9
+            gbyte = bpt[k] * ntok / 1e9
+            t_mfma, t_hbm = gflop / (peak * 1e3), gbyte / HBM_PEAK_GBS
+            if t_mfma >= t_hbm:
+                return {"bound": "mfma", "achieved": gflop / ms, "peak": peak, "unit": "TFLOP/s", "frac": gflop / ms / peak}
+            return {"bound": "hbm", "achieved": gbyte / (ms * 1e-3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbyte / (ms * 1e-3) / HBM_PEAK_GBS}
+
+        flops_patch = sum(fpt[k] * (V * H * W) * c for k, (_, c) in kb.items())
         result = {
             "metric": f"LF patches/sec ({A}x{A} angRes, {H}x{W} LR, {S}xSR)",
             "value": world * args.batch * args.steps / dt,
@@ -183,12 +219,14 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"LFT {A}x{A} angRes {S}xSR inference, batch={args.batch} per GPU, {H}x{W} LR patches",
                        "global_batch": world * args.batch, "parallelism": f"dp{world} (independent shards)",
+                       "streams_per_gpu": args.streams, "hip_graph": not args.no_graph,
                        "algorithmic_gflop_per_patch": flops_patch / 1e9},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
-                         "launch_ms": dom_ms, "launches_per_forward": dom_cnt, "gpu_ms_per_forward": total_ms,
-                         "kernels": {k: {"ms": round(ms, 4), "n": c, "tflops": round(fpt[k] * (units if k == dom else (args.batch * A * H * S * A * W * S if k == "k_assemble" else ntok)) / (ms * 1e-3) / 1e12, 2)}
-                                     for k, (ms, c) in kb.items()}},
+            "roofline": dict(roof(dom, dom_ms), kernel=dom, traffic=None, launch_ms=dom_ms, launches_per_forward=dom_cnt,
+                             gpu_ms_per_forward=total_ms,
+                             algorithmic_per_launch={"gflop": fpt[dom] * ntok / 1e9, "gbyte": bpt[dom] * ntok / 1e9},
+                             kernels={k: dict(ms=round(ms, 4), n=c, **{kk: (round(vv, 3) if isinstance(vv, float) else vv)
+                                                                         for kk, vv in roof(k, ms).items() if kk in ("bound", "achieved", "frac")})
+                                      for k, (ms, c) in kb.items()}),
         }
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle on host cores ...")

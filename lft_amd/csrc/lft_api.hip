@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -123,12 +124,20 @@ constexpr size_t kLdsParams = 1024;   // 256 LayerNorm floats
 template <typename T> size_t lds_spa1(int w) { return WRing<T, kSpaChunk>::LDS_BYTES + ConvIn<T>::bytes(w) + kLdsParams; }
 template <typename T> size_t lds_ring() { return WRing<T, kSpaChunk>::LDS_BYTES + kLdsParams; }
 template <typename T> size_t lds_spa2() { return WRing<T, kSpaChunk>::LDS_BYTES + kLdsParams + 4 * TileIO<4, T>::BYTES; }
-template <typename T> size_t lds_up() { return WRing<T, kSpaChunk>::LDS_BYTES + 4 * TileIO<2, T>::BYTES; }
+template <typename T> size_t lds_up() { return WRing<T, kUpChunk>::LDS_BYTES + 4 * TileIO<2, T>::BYTES; }
 template <typename T> size_t lds_ang() { return (size_t)kFragsAng * 1024 * FragInfo<T>::PIECES + kLdsParams + 4 * TileIO<2, T>::BYTES; }
 constexpr size_t kMaxLds = 160 * 1024;
 template <typename K> int allow_lds(K kernel, size_t bytes, const char* name) {
     if (bytes > kMaxLds) return fail(LFT_ERR_SHAPE, "%s needs %zu B of LDS (> 160 KiB): view width too large for this build", name, bytes);
-    if (bytes > 64 * 1024) LFT_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes <= 64 * 1024) return 0;
+    // The attribute is sticky per kernel: set it once per (kernel, size) so that steady-state forwards -- and a
+    // stream capture of them -- consist of kernel launches only.
+    static thread_local std::vector<std::pair<const void*, size_t>> done;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    for (const auto& d : done)
+        if (d.first == fn && d.second >= bytes) return 0;
+    LFT_HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done.emplace_back(fn, bytes);
     return 0;
 }
 

@@ -189,7 +189,10 @@ LFT_DEV void conv3x3_tile(const char* lds_in, int tl, int y, int x, bool ok, int
 }
 
 // conv_init[i]: 64 -> 64 + LeakyReLU(0.2); the last one adds conv_init0's output (reference LFT.py:26-33,66).
-constexpr int kConv64Chunk = 12;   // 72 fragments = 6 chunks; 3-slot ring = 36 KiB (bf16) so two workgroups share a CU
+#ifndef LFT_CONV64_CHUNK
+#define LFT_CONV64_CHUNK 12
+#endif
+constexpr int kConv64Chunk = LFT_CONV64_CHUNK;   // 72 fragments = 6 chunks; 3-slot ring = 36 KiB (bf16) so two workgroups share a CU
 template <typename T, bool RES>
 __global__ __launch_bounds__(256) void k_conv64(const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ res,
                                                 const T* __restrict__ wstream, int nimg, int h, int w) {

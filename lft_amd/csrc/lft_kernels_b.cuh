@@ -12,6 +12,10 @@
 // Stream: conv[36 x 4] Wv[4x8] Wq[4x8] Wk[4x8]  (240 fragments).
 // PE_ONLY: embed the position image itself and write the tokens (pack-time precompute).
 // ------------------------------------------------------------------------------------------
+#ifndef LFT_UP_CHUNK
+#define LFT_UP_CHUNK 8
+#endif
+constexpr int kUpChunk = LFT_UP_CHUNK;    // k_up uses few registers: a smaller ring lets more workgroups share a CU
 constexpr int kSpaChunk = 16;   // fragments per ring chunk: one conv tap (4 k-steps x 4 row tiles), half an in_proj matrix
 template <typename T, bool PE_ONLY>
 __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
@@ -432,10 +436,10 @@ __global__ __launch_bounds__(256) void k_up(const T* __restrict__ X, const T* __
     const long long tok = ok ? tok_raw : ntok - 1;
     const long long t0 = tok_raw - r;
     const int nvalid = (int)max(0LL, min(32LL, ntok - t0));
-    char* scr = smem + WRing<T, kSpaChunk>::LDS_BYTES + (threadIdx.x >> 6) * TileIO<2, T>::BYTES;
+    char* scr = smem + WRing<T, kUpChunk>::LDS_BYTES + (threadIdx.x >> 6) * TileIO<2, T>::BYTES;
     f32x16 x[2];
     load_tile<2, T>(X + min(t0, ntok - 1) * 64, nvalid, lane, x, scr);
-    WRing<T, kSpaChunk> ring;
+    WRing<T, kUpChunk> ring;
     ring.init(ws, smem, nchunk * (4 + 2 * GT));
     Frag<T> xf[4];
     acc_frags<2, T>(x, xf);

@@ -43,8 +43,11 @@ class get_model(nn.Module):
     fp32 accumulation).  May also be given as ``args.lft_precision``.
     """
 
-    def __init__(self, args, precision: Optional[str] = None):
+    def __init__(self, args, precision: Optional[str] = None, streams: Optional[int] = None):
         super().__init__()
+        # Patches never interact, so a batch can be split over several HIP streams: the kernels of one sub-batch
+        # (e.g. the VALU-bound windowed attention) then overlap the MFMA-bound kernels of another.
+        self.streams = int(streams if streams is not None else getattr(args, "lft_streams", 2))
         self.channels = int(args.channels)
         self.angRes = int(args.angRes)
         self.factor = int(args.scale_factor)
@@ -66,7 +69,8 @@ class get_model(nn.Module):
             _attach(self, name, nn.Parameter(t))
             self._names.append(name)
         self._packed = None        # (key, tensor)
-        self._work = None          # (key, tensor)
+        self._work = {}            # slot -> (key, tensor)
+        self._side_streams = {}    # device -> [torch.cuda.Stream]
 
     # ------------------------------------------------------------------ packing / buffers
     def _params_in_order(self):
@@ -92,12 +96,14 @@ class get_model(nn.Module):
             self._packed = (key, buf)
         return self._packed[1]
 
-    def _ensure_work(self, dev, B, h, w, prec):
+    def _ensure_work(self, dev, B, h, w, prec, slot=0):
         key = (str(dev), B, h, w, prec)
-        if self._work is None or self._work[0] != key:
+        cur = self._work.get(slot)
+        if cur is None or cur[0] != key:
             nbytes = _lib.workspace_bytes(B, self.angRes, h, w, self.factor, prec)
-            self._work = (key, torch.empty(nbytes, dtype=torch.uint8, device=dev))
-        return self._work[1]
+            cur = (key, torch.empty(nbytes, dtype=torch.uint8, device=dev))
+            self._work[slot] = cur
+        return cur[1]
 
     # ------------------------------------------------------------------ forward
     def forward(self, lr: torch.Tensor) -> torch.Tensor:
@@ -118,12 +124,59 @@ class get_model(nn.Module):
         prec = _PREC[self.precision]
         stream = torch.cuda.current_stream(x.device).cuda_stream
         with torch.cuda.device(x.device):
+            main = torch.cuda.current_stream(x.device)
             packed = self._ensure_packed(x.device, h, w, prec, stream)
-            work = self._ensure_work(x.device, B, h, w, prec)
             out = torch.empty((B, 1, H * s, W * s), dtype=torch.float32, device=x.device)
-            _lib.check(_lib.lib().lft_forward(packed.data_ptr(), x.data_ptr(), out.data_ptr(), work.data_ptr(),
-                                              B, A, h, w, s, prec, stream), "lft_forward")
+            nsplit = max(1, min(self.streams, B))
+            if nsplit == 1:
+                work = self._ensure_work(x.device, B, h, w, prec)
+                _lib.check(_lib.lib().lft_forward(packed.data_ptr(), x.data_ptr(), out.data_ptr(), work.data_ptr(),
+                                                  B, A, h, w, s, prec, stream), "lft_forward")
+            else:
+                side = self._side_streams.setdefault(x.device, [])
+                while len(side) < nsplit:
+                    side.append(torch.cuda.Stream(device=x.device))
+                ready = torch.cuda.Event()
+                ready.record(main)                      # inputs, packed weights and `out` are ordered on the caller's stream
+                from .dp import shard_range
+                for i in range(nsplit):
+                    b0, b1 = shard_range(B, i, nsplit)
+                    st = side[i]
+                    st.wait_event(ready)
+                    work = self._ensure_work(x.device, b1 - b0, h, w, prec, slot=i)
+                    _lib.check(_lib.lib().lft_forward(packed.data_ptr(), x[b0:b1].data_ptr(), out[b0:b1].data_ptr(), work.data_ptr(),
+                                                      b1 - b0, A, h, w, s, prec, st.cuda_stream), "lft_forward")
+                    main.wait_stream(st)                # the caller's stream sees the finished sub-batch
         return out
+
+
+class GraphedForward:
+    """Replay of one captured forward (HIP graph) for a fixed input shape: the ~22 launches per sub-batch and the
+    stream fork/join become a single graph launch.  Inference only; weights must not change between replays
+    (re-create after load_state_dict / optimizer steps).  Usage: g = GraphedForward(net, example_lr); out = g(lr)."""
+
+    def __init__(self, net: "get_model", example: torch.Tensor, warmup: int = 3):
+        self.net = net
+        self.static_in = example.detach().clone().contiguous()
+        with torch.no_grad():
+            s = torch.cuda.Stream(device=example.device)
+            s.wait_stream(torch.cuda.current_stream(example.device))
+            with torch.cuda.stream(s):
+                for _ in range(warmup):                # packs weights, sizes buffers, sets kernel attributes
+                    net(self.static_in)
+            torch.cuda.current_stream(example.device).wait_stream(s)
+            torch.cuda.synchronize(example.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_out = net(self.static_in)
+
+    def __call__(self, lr: torch.Tensor) -> torch.Tensor:
+        if lr.shape != self.static_in.shape:
+            raise ValueError(f"graph was captured for {tuple(self.static_in.shape)}, got {tuple(lr.shape)}")
+        if lr.data_ptr() != self.static_in.data_ptr():
+            self.static_in.copy_(lr)
+        self.graph.replay()
+        return self.static_out
 
 
 class get_loss(nn.Module):
