@@ -82,6 +82,16 @@ int lft_spa_block_fwd(const void* packed, int layer, const void* act_in, const v
 /* upsampling + bicubic skip, reference LFT.py:79-81: act_in [B,V,h,w,64] -> out fp32 [B,1,A*h*s,A*w*s]. */
 int lft_upsample_fwd(const void* packed, const void* act_in, const float* lr, float* out, void* workspace,
                      int B, int A, int h, int w, int s, int prec, void* stream);
+/* ---- scene tiling around the hot path (reference utils/utils.py:91-157; caller = test.py:83-101) ----
+ * lft_scene_counts   : numU, numV of LFdivide for a scene of A x A views of h0 x w0 (utils.py:95-105).
+ * lft_scene_divide   : LFdivide -- scene mosaic fp32 [A*h0, A*w0] -> patches fp32 [numU*numV, 1, A*patch, A*patch]
+ *                      (mirror-extended by (patch-stride)/2, zero fill beyond), ready to be fed to lft_forward as a batch.
+ * lft_scene_integrate: LFintegrate + re-mosaic (test.py:97-101) -- SR patches [numU*numV, 1, A*patch*s, A*patch*s]
+ *                      -> SR scene mosaic [A*h0*s, A*w0*s], keeping the central stride*s region of every patch. */
+int lft_scene_counts(int h0, int w0, int patch, int stride, int* num_u, int* num_v);
+int lft_scene_divide(const float* scene, float* patches, int A, int h0, int w0, int patch, int stride, void* stream);
+int lft_scene_integrate(const float* sr_patches, float* sr_scene, int A, int h0, int w0, int patch, int stride, int s, void* stream);
+
 /* Debug aid: a single conv_init[which] launch (with_res: add `res`; extra_lds: pad the LDS request). */
 int lft_debug_conv64(const void* packed, int which, int with_res, const void* in, const void* res, void* out,
                      int B, int A, int h, int w, int s, int prec, int extra_lds, void* stream);

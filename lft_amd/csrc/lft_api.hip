@@ -534,6 +534,37 @@ int lft_debug_clear_stamps(void) {
 }
 #endif
 
+static int scene_counts(int h0, int w0, int patch, int stride, int* nu, int* nv) {
+    if (h0 < 1 || w0 < 1 || patch < 1 || stride < 1 || stride > patch) return fail(LFT_ERR_SHAPE, "bad scene tiling (h0=%d w0=%d patch=%d stride=%d)", h0, w0, patch, stride);
+    const int bdr = (patch - stride) / 2, h = h0 + 2 * bdr, w = w0 + 2 * bdr;
+    if (h < patch || w < patch) return fail(LFT_ERR_SHAPE, "view %dx%d is smaller than one patch after extension", h0, w0);
+    *nu = (h - patch) / stride + ((h - patch) % stride ? 2 : 1);
+    *nv = (w - patch) / stride + ((w - patch) % stride ? 2 : 1);
+    return 0;
+}
+int lft_scene_counts(int h0, int w0, int patch, int stride, int* num_u, int* num_v) {
+    if (!num_u || !num_v) return fail(LFT_ERR_ARG, "null pointer");
+    return scene_counts(h0, w0, patch, stride, num_u, num_v);
+}
+int lft_scene_divide(const float* scene, float* patches, int A, int h0, int w0, int patch, int stride, void* stream) {
+    int nu, nv, rc;
+    if (!scene || !patches || A < 1) return fail(LFT_ERR_ARG, "bad argument");
+    if ((rc = scene_counts(h0, w0, patch, stride, &nu, &nv))) return rc;
+    const dim3 grid((unsigned)((A * patch + 255) / 256), (unsigned)(A * patch), (unsigned)(nu * nv));
+    k_scene_divide<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(scene, patches, A, h0, w0, patch, stride, nv);
+    LFT_LAUNCH_OK("k_scene_divide");
+    return 0;
+}
+int lft_scene_integrate(const float* sr_patches, float* sr_scene, int A, int h0, int w0, int patch, int stride, int s, void* stream) {
+    int nu, nv, rc;
+    if (!sr_patches || !sr_scene || A < 1 || s < 1) return fail(LFT_ERR_ARG, "bad argument");
+    if ((rc = scene_counts(h0, w0, patch, stride, &nu, &nv))) return rc;
+    const dim3 grid((unsigned)((A * w0 * s + 255) / 256), (unsigned)(A * h0 * s));
+    k_scene_integrate<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(sr_patches, sr_scene, A, patch * s, stride * s, h0 * s, w0 * s, nv);
+    LFT_LAUNCH_OK("k_scene_integrate");
+    return 0;
+}
+
 int lft_mfma_selftest(const float* Am, const float* Bm, const float* W2, float* C, float* D, int prec, void* stream) {
     if (!Am || !Bm || !W2 || !C || !D) return fail(LFT_ERR_ARG, "null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -534,6 +534,42 @@ __global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ lr, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Scene tiling around the hot path (reference utils/utils.py:91-157, driven by test.py:83-101): a whole scene is
+// cut into overlapping A*patch x A*patch mosaics on the GPU, super-resolved as ONE batch, and re-assembled from
+// the central stride*s region of every SR patch -- instead of the reference's batch-1 Python double loop.
+// Both kernels are pure gathers (one thread per output element), HBM-bound.
+// ------------------------------------------------------------------------------------------
+LFT_DEV int reflect_idx(int i, int n) {             // symmetric extension, edge repeated (ImageExtend, utils.py:126-138)
+    i = i < 0 ? -i - 1 : i;
+    return i >= n ? 2 * n - 1 - i : i;
+}
+__global__ __launch_bounds__(256) void k_scene_divide(const float* __restrict__ scene, float* __restrict__ patches,
+                                                      int A, int h0, int w0, int patch, int stride, int nv) {
+    // grid: x over the A*patch columns, y = row of the patch mosaic, z = patch index ku*nv + kv
+    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y, n = blockIdx.z;
+    const int P = A * patch;
+    if (X >= P) return;
+    const int bdr = (patch - stride) / 2, ku = n / nv, kv = n - ku * nv;
+    const int u = Y / patch, y = Y - u * patch, v = X / patch, x = X - v * patch;
+    const int ey = ku * stride + y, ex = kv * stride + x;
+    float val = 0.0f;                                   // beyond the extended view: zero fill (utils.py:109-113)
+    if (ey < h0 + 2 * bdr && ex < w0 + 2 * bdr)
+        val = scene[(size_t)(u * h0 + reflect_idx(ey - bdr, h0)) * (A * w0) + v * w0 + reflect_idx(ex - bdr, w0)];
+    patches[((size_t)n * P + Y) * P + X] = val;
+}
+__global__ __launch_bounds__(256) void k_scene_integrate(const float* __restrict__ sub, float* __restrict__ out,
+                                                         int A, int pz, int stride, int h0, int w0, int nv) {
+    // grid: x over the A*w0 columns of the SR scene mosaic, y = its rows; pz, stride, h0, w0 are in SR pixels
+    const int Xm = blockIdx.x * 256 + threadIdx.x, Ym = blockIdx.y;
+    if (Xm >= A * w0) return;
+    const int bdr = (pz - stride) / 2;
+    const int u = Ym / h0, Y = Ym - u * h0, v = Xm / w0, X = Xm - v * w0;
+    const int ku = Y / stride, i = Y - ku * stride, kv = X / stride, j = X - kv * stride;
+    const int P = A * pz;
+    out[(size_t)Ym * (A * w0) + Xm] = sub[((size_t)(ku * nv + kv) * P + u * pz + bdr + i) * P + v * pz + bdr + j];
+}
+
+// ------------------------------------------------------------------------------------------
 // MFMA layout self-test: C[32x32] = A[32x16] * B[16x32] through the same fragment helpers the
 // kernels use (natural k order), and the acc-order re-use path D = W2 * C.  Checked from Python
 // with asymmetric integer data (guide rule: never validate a layout with symmetric operands).

@@ -221,3 +221,55 @@ def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
 
 def state_from_numpy(sd_np) -> Dict[str, torch.Tensor]:
     return {k: torch.from_numpy(v) for k, v in sd_np.items()}
+
+
+# --------------------------------------------------------------------------------------------
+# Scene tiling around the hot path (reference utils/utils.py:91-157, used by test.py:83-101)
+# --------------------------------------------------------------------------------------------
+def _reflect(i: torch.Tensor, n: int) -> torch.Tensor:
+    """Symmetric extension index (edge pixel repeated), as ImageExtend's flipped copies give
+    (reference utils.py:126-138): -1 -> 0, -2 -> 1, n -> n-1, n+1 -> n-2."""
+    i = torch.where(i < 0, -i - 1, i)
+    return torch.where(i >= n, 2 * n - 1 - i, i)
+
+
+def lf_divide_counts(h0: int, w0: int, patch: int, stride: int):
+    """numU, numV of LFdivide (reference utils.py:95-105)."""
+    bdr = (patch - stride) // 2
+    h, w = h0 + 2 * bdr, w0 + 2 * bdr
+    nu = (h - patch) // stride + (2 if (h - patch) % stride else 1)
+    nv = (w - patch) // stride + (2 if (w - patch) % stride else 1)
+    return nu, nv
+
+
+def lf_divide(data: torch.Tensor, A: int, patch: int, stride: int) -> torch.Tensor:
+    """LFdivide (reference utils.py:91-123): scene mosaic [A*h0, A*w0] -> [numU, numV, A*patch, A*patch].
+    Every view is mirror-extended by bdr = (patch-stride)//2, zero-filled up to the last patch, and cut into
+    patch x patch crops with the given stride."""
+    h0, w0 = data.shape[0] // A, data.shape[1] // A
+    bdr = (patch - stride) // 2
+    nu, nv = lf_divide_counts(h0, w0, patch, stride)
+    views = data.reshape(A, h0, A, w0).permute(0, 2, 1, 3)                    # [u, v, h0, w0]
+    ey = (torch.arange(nu).view(-1, 1) * stride + torch.arange(patch).view(1, -1))   # [nu, patch] extended-image rows
+    ex = (torch.arange(nv).view(-1, 1) * stride + torch.arange(patch).view(1, -1))
+    oky, okx = ey < h0 + 2 * bdr, ex < w0 + 2 * bdr
+    sy, sx = _reflect(ey - bdr, h0).clamp(0, h0 - 1), _reflect(ex - bdr, w0).clamp(0, w0 - 1)
+    g = views[:, :, sy][:, :, :, :, sx]                                        # [u, v, nu, patch, nv, patch]
+    g = g * (oky.view(1, 1, nu, patch, 1, 1) & okx.view(1, 1, 1, 1, nv, patch)).to(g.dtype)
+    return g.permute(2, 4, 0, 3, 1, 5).reshape(nu, nv, A * patch, A * patch)
+
+
+def lf_integrate(sub: torch.Tensor, A: int, pz: int, stride: int, h0: int, w0: int) -> torch.Tensor:
+    """LFintegrate (reference utils.py:141-157): [numU, numV, A*pz, A*pz] -> [A, A, h0, w0], keeping the central
+    stride x stride region of every patch (pz, stride, h0, w0 already multiplied by the scale factor)."""
+    nu, nv = sub.shape[:2]
+    bdr = (pz - stride) // 2
+    s = sub.reshape(nu, nv, A, pz, A, pz)[:, :, :, bdr:bdr + stride, :, bdr:bdr + stride]     # [ku, kv, u, i, v, j]
+    t = s.permute(2, 4, 0, 3, 1, 5).reshape(A, A, nu * stride, nv * stride)
+    return t[:, :, :h0, :w0].contiguous()
+
+
+def views_to_scene_mosaic(x: torch.Tensor) -> torch.Tensor:
+    """[A, A, H, W] -> [A*H, A*W] (reference test.py:100-101)."""
+    A, _, H, W = x.shape
+    return x.permute(0, 2, 1, 3).reshape(A * H, A * W)

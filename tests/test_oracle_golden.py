@@ -68,3 +68,18 @@ def test_bicubic_and_loss(golden_dir):
         assert np.abs(O.bicubic_skip(x, 3, s).numpy() - g[f"bicubic_a3_7x5_s{s}"]).max() <= 1e-6
     a, b = torch.from_numpy(g["l1_pair"][0]), torch.from_numpy(g["l1_pair"][1])
     assert abs(float(O.l1_loss(a, b)) - float(g["l1_value"])) <= 1e-7
+
+
+def test_scene_tiling_matches_reference(golden_dir):
+    """LFdivide / LFintegrate restatement (oracle) vs outputs of the reference functions (utils/utils.py:91-157)."""
+    g = np.load(os.path.join(golden_dir, "tiling.npz"))
+    for name in ("a2_50x41", "a3_32x48", "a2_20x23_p8"):
+        A, h0, w0, patch, stride, s, nu, nv = [int(v) for v in g[f"{name}_meta"]]
+        rng = np.random.Generator(np.random.PCG64([11, A, h0, w0]))
+        scene = torch.from_numpy(rng.random((A * h0, A * w0), dtype=np.float32))
+        assert O.lf_divide_counts(h0, w0, patch, stride) == (nu, nv)
+        sub = O.lf_divide(scene, A, patch, stride)
+        assert np.array_equal(sub.numpy(), g[f"{name}_divide"])
+        srp = torch.from_numpy(rng.random((nu, nv, A * patch * s, A * patch * s), dtype=np.float32))
+        out = O.lf_integrate(srp, A, patch * s, stride * s, h0 * s, w0 * s)
+        assert np.array_equal(out.numpy(), g[f"{name}_integrate"])

@@ -102,11 +102,42 @@ def misc(ref):
     print(f"misc -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def load_reference_tiling():
+    """LFdivide / ImageExtend / LFintegrate are pure torch, but utils/utils.py also imports skimage and the argparse
+    singleton.  Compile just those three function definitions out of the file (no stand-in modules)."""
+    import ast
+    src = open("/root/reference/utils/utils.py").read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("LFdivide", "ImageExtend", "LFintegrate")]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "reference_utils_subset", "exec"), ns)
+    return ns
+
+
+def tiling(ns):
+    rec = {}
+    for name, (A, h0, w0, patch, stride, s) in {"a2_50x41": (2, 50, 41, 32, 16, 2), "a3_32x48": (3, 32, 48, 32, 16, 4),
+                                                "a2_20x23_p8": (2, 20, 23, 8, 4, 2)}.items():
+        rng = np.random.Generator(np.random.PCG64([11, A, h0, w0]))
+        scene = torch.from_numpy(rng.random((A * h0, A * w0), dtype=np.float32))
+        sub = ns["LFdivide"](scene, A, patch, stride)
+        nu, nv = sub.shape[:2]
+        srp = torch.from_numpy(rng.random((nu, nv, A * patch * s, A * patch * s), dtype=np.float32))
+        out = ns["LFintegrate"](srp, A, patch * s, stride * s, h0 * s, w0 * s)
+        rec[f"{name}_meta"] = np.array([A, h0, w0, patch, stride, s, nu, nv], dtype=np.int64)
+        rec[f"{name}_divide"] = sub.numpy()
+        rec[f"{name}_integrate"] = out.numpy()
+    path = os.path.join(ROOT, "tests", "golden", "tiling.npz")
+    np.savez_compressed(path, **rec)
+    print(f"tiling -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def main():
     torch.set_num_threads(8)
     ref = load_reference()
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     misc(ref)
+    tiling(load_reference_tiling())
     run_case(ref, "tiny_a5_s2_b2_6x6", 5, 2, 2, 6, 6, full_taps=True)       # per-stage activations in full
     run_case(ref, "small_a5_s4_b1_8x8", 5, 4, 1, 8, 8)
     run_case(ref, "small_a9_s4_b1_8x8", 9, 4, 1, 8, 8)
