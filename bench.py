@@ -119,6 +119,21 @@ def cpu_baseline(seconds: float):
             "sample": f"{n} single-patch forwards (A5, 4x, 32x32 LR, fp32, torch {torch.__version__} CPU ops) in {dt:.1f} s"}
 
 
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_v5_hbm_traffic.json")
+
+
+def traffic_from_profile(kernel: str, args) -> dict:
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+    runs, gfx950 correction; tools/collect_traffic.py).  PMC counters cannot be read from inside this process, so
+    the value is only reported for the exact workload the profile was taken on; otherwise null."""
+    default = (A, S, H, W, args.batch, args.precision) == (5, 4, 32, 32, 4, "bf16")
+    if default and os.path.exists(TRAFFIC_PROFILE):
+        k = json.load(open(TRAFFIC_PROFILE))["kernels"].get(kernel)
+        if k:
+            return {"traffic": k["total"], "traffic_source": "profiles/r01_v5_hbm_traffic.json"}
+    return {"traffic": None}
+
+
 def note(msg: str) -> None:
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -221,7 +236,7 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world} (independent shards)",
                        "streams_per_gpu": args.streams, "hip_graph": not args.no_graph,
                        "algorithmic_gflop_per_patch": flops_patch / 1e9},
-            "roofline": dict(roof(dom, dom_ms), kernel=dom, traffic=None, launch_ms=dom_ms, launches_per_forward=dom_cnt,
+            "roofline": dict(roof(dom, dom_ms), kernel=dom, **traffic_from_profile(dom, args), launch_ms=dom_ms, launches_per_forward=dom_cnt,
                              gpu_ms_per_forward=total_ms,
                              algorithmic_per_launch={"gflop": fpt[dom] * ntok / 1e9, "gbyte": bpt[dom] * ntok / 1e9},
                              kernels={k: dict(ms=round(ms, 4), n=c, **{kk: (round(vv, 3) if isinstance(vv, float) else vv)

@@ -316,8 +316,12 @@ int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, con
                                                          tok, q, k, v, nullptr, nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_spa1");
     if constexpr (sizeof(T) == 2) {
-        const dim3 grid((unsigned)(nimg * ((d.h + kAttTY - 1) / kAttTY) * ((d.w + kAttTX - 1) / kAttTX)), 2);
-        k_spa_attn_lds<<<grid, 512, kAttLds, st>>>(q, k, v, o, d.h, d.w);
+        const unsigned ntile = (unsigned)(nimg * ((d.h + kAttTY - 1) / kAttTY) * ((d.w + kAttTX - 1) / kAttTX));
+#ifdef LFT_ATT_VALU       // A/B: the LDS-tiled VALU (v_dot2c) kernel
+        k_spa_attn_lds<<<dim3(ntile, 2), kAttThreads, kAttLds, st>>>(q, k, v, o, d.h, d.w);
+#else
+        k_spa_attn_mfma<<<ntile, 256, kAmLds, st>>>(q, k, v, o, d.h, d.w);
+#endif
     } else {
         k_spa_attn<T><<<blocks_for(d.ntok * 8, 256), 256, 0, st>>>(q, k, v, o, d.ntok, d.h, d.w);
     }

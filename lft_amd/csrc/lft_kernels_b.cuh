@@ -230,14 +230,18 @@ __global__ __launch_bounds__(256) void k_spa_attn<bf16_t>(const bf16_t* __restri
 // The (4+4) x (32+4) halo tile of K -- then of V, re-using the same 41 KiB -- is staged once into LDS (every key is
 // used by up to 25 queries x 4 heads), token rows padded to 144 B so the 16-byte reads of a half-wave (32 different
 // query columns) fall on distinct banks.  wave = (head, 2 query rows), lane = (row parity, column).
-constexpr int kAttTY = 4, kAttTX = 32, kAttHR = kAttTY + 4, kAttHC = kAttTX + 4, kAttRow = 144;
+#ifndef LFT_ATT_TY
+#define LFT_ATT_TY 4
+#endif
+constexpr int kAttTY = LFT_ATT_TY, kAttTX = 32, kAttHR = kAttTY + 4, kAttHC = kAttTX + 4, kAttRow = 144;
+constexpr int kAttThreads = kAttTY * kAttTX * 4;      // one thread per (query, head) for 4 heads
 constexpr int kAttLds = kAttHR * kAttHC * kAttRow;
 LFT_DEV void att_stage(const bf16_t* __restrict__ src, char* lds, long long img_tok0, int ty, int tx, int hg, int h, int w) {
-    constexpr int N = kAttHR * kAttHC * 8, ITER = (N + 511) / 512;       // 2304 16-byte pieces, 5 per thread
+    constexpr int N = kAttHR * kAttHC * 8, ITER = (N + kAttThreads - 1) / kAttThreads;   // 16-byte pieces of the halo tile
     raw16 v[ITER];
 #pragma unroll
     for (int u = 0; u < ITER; ++u) {                                       // all loads first (branch-free), then all stores
-        const int idx = min((int)threadIdx.x + 512 * u, N - 1);
+        const int idx = min((int)threadIdx.x + kAttThreads * u, N - 1);
         const int slot = idx >> 3, piece = idx & 7;
         const int gy = ty * kAttTY - 2 + slot / kAttHC, gx = tx * kAttTX - 2 + slot % kAttHC;
         const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
@@ -247,7 +251,7 @@ LFT_DEV void att_stage(const bf16_t* __restrict__ src, char* lds, long long img_
     }
 #pragma unroll
     for (int u = 0; u < ITER; ++u) {
-        const int idx = (int)threadIdx.x + 512 * u;
+        const int idx = (int)threadIdx.x + kAttThreads * u;
         if (idx < N) store_raw16(lds + (idx >> 3) * kAttRow + (idx & 7) * 16, v[u]);
     }
 }
@@ -256,7 +260,7 @@ LFT_DEV void lds_pairs16(const char* p, bf16x2 (&o)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o[i] = bf16x2{a[2 * i], a[2 * i + 1]}; o[4 + i] = bf16x2{b[2 * i], b[2 * i + 1]}; }
 }
-__global__ __launch_bounds__(512) void k_spa_attn_lds(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(kAttThreads) void k_spa_attn_lds(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                       const bf16_t* __restrict__ Vv, bf16_t* __restrict__ O, int h, int w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_x = (w + kAttTX - 1) / kAttTX, tiles_y = (h + kAttTY - 1) / kAttTY;
@@ -360,6 +364,174 @@ __global__ __launch_bounds__(512) void k_spa_attn_lds(const bf16_t* __restrict__
 #pragma unroll
     for (int g = 0; g < 4; ++g)
         store4(O + tok * 128 + hg * 64 + hl * 16 + 4 * g, f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv});
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA windowed attention (bf16 production path; same maths as the two kernels above).
+// A workgroup = a 4 x 32 tile of queries of one view image; wave c owns the 8 x 4 block of columns 8c..8c+7
+// (32 queries on its 32 MFMA columns).  The block's clamped 5x5 windows live inside a 12 x 8 neighbourhood =
+// 96 keys = three 32-key tiles.  Per pair of heads (32 channels) the K and V halo tiles (8 x 36 tokens) are
+// staged in LDS once for the four waves, then per head
+//   S^T[key, q]  = K_tile . Q^T          3 MFMAs (head_dim 16 = exactly one k-step); the accumulator is
+//                                        initialised with a 0 / -inf bias that encodes window, image border
+//                                        and the reference's min(h, x+3) column clamp (LFT.py:155)
+//   softmax over the 96 rows             in registers + one lane^32 exchange (raw v_exp_f32)
+//   O^T[d, q]   += V^T_tile . P^T        6 MFMAs; V^T operand fragments come straight out of the row-major LDS
+//                                        tile through ds_read_b64_tr_b16 (hardware transposing read)
+// i.e. the dot products run on the matrix pipe and the VALU only does the softmax: about half the VALU
+// instructions per query of the dot2c kernel above, which was VALU-issue-bound.
+// ------------------------------------------------------------------------------------------
+constexpr int kAmRow = 80;                                   // 32 channels (2 heads) x bf16 + 16 B pad per staged token
+constexpr int kAmSlots = kAttHR * kAttHC;                    // 8 x 36 halo tokens (kAttTY = 4, kAttTX = 32)
+constexpr int kAmLds = 2 * kAmSlots * kAmRow;                // K tile + V tile
+static_assert(LFT_ATT_TY == 4, "k_spa_attn_mfma is written for 4-row tiles");
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// Per-thread staging plan of the 8 x 36 x (2 heads) halo tile: which global token / LDS slot each of the thread's
+// 16-byte pieces touches.  Independent of the head pair, so it is computed once per workgroup tile.
+struct AmPlan {
+    static constexpr int N = kAmSlots * 4, ITER = (N + 255) / 256;      // 16-byte pieces: 4 per token
+    long long gofs[ITER];                                               // element offset of the piece in Q/K/V ([tok][128]), head pair 0
+    int lofs[ITER];                                                     // byte offset in the LDS tile (or -1: no store)
+    unsigned inmask;                                                    // bit u: the token exists in the image
+};
+LFT_DEV void am_plan(AmPlan& p, long long img0, int y0, int x0, int h, int w) {
+    p.inmask = 0;
+#pragma unroll
+    for (int u = 0; u < AmPlan::ITER; ++u) {
+        const int raw = (int)threadIdx.x + 256 * u, idx = min(raw, AmPlan::N - 1);
+        const int slot = idx >> 2, piece = idx & 3;
+        const int gy = y0 - 2 + slot / kAttHC, gx = x0 - 2 + slot % kAttHC;
+        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+        p.gofs[u] = (in ? img0 + gy * w + gx : img0) * 128 + piece * 8;
+        p.lofs[u] = raw < AmPlan::N ? slot * kAmRow + piece * 16 : -1;
+        p.inmask |= (in ? 1u : 0u) << u;
+    }
+}
+LFT_DEV void am_load(const AmPlan& p, const bf16_t* __restrict__ src, int hg, raw16 (&v)[AmPlan::ITER]) {
+#pragma unroll
+    for (int u = 0; u < AmPlan::ITER; ++u) {
+        const raw16 r = load_raw16(reinterpret_cast<const char*>(src + p.gofs[u] + hg * 32));
+        v[u] = ((p.inmask >> u) & 1u) ? r : raw16{0u, 0u, 0u, 0u};
+    }
+}
+LFT_DEV void am_store(const AmPlan& p, char* lds, const raw16 (&v)[AmPlan::ITER]) {
+#pragma unroll
+    for (int u = 0; u < AmPlan::ITER; ++u)
+        if (p.lofs[u] >= 0) store_raw16(lds + p.lofs[u], v[u]);
+}
+
+__global__ __launch_bounds__(256, 2) void k_spa_attn_mfma(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                          const bf16_t* __restrict__ Vv, bf16_t* __restrict__ O, int h, int w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsK = smem;
+    char* ldsV = smem + kAmSlots * kAmRow;
+    const int tiles_x = (w + kAttTX - 1) / kAttTX, tiles_y = (h + kAttTY - 1) / kAttTY;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, im = blockIdx.x / (tiles_x * tiles_y);
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int y0 = ty * kAttTY, x0 = tx * kAttTX, bxl = 8 * wave;          // block origin: (y0, x0 + bxl)
+    const long long img0 = (long long)im * h * w;
+    AmPlan plan;
+    am_plan(plan, img0, y0, x0, h, w);
+    // this lane's query
+    const int qy = y0 + (r >> 3), qx = x0 + bxl + (r & 7);
+    const bool qok = qy < h && qx < w;
+    const long long qtok = img0 + min(qy, h - 1) * w + min(qx, w - 1);
+    // 0 / -inf bias of the three score tiles: key kk = 32 j + row -> (jy, jx) = (kk / 12, kk % 12) of the 12 x 8 neighbourhood
+    f32x16 bias[3];
+    {
+        const int wy0 = max(0, qy - 2), wy1 = min(h, qy + 3), wx0 = max(0, qx - 2), wx1 = min(min(h, qx + 3), w);   // reference LFT.py:155 (sic)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k0 = 32 * j + acc_row(i, 0), k1 = k0 + 4;          // key index for lane half 0 / 1 (compile-time)
+                const int ky = y0 - 2 + (hh ? k1 / 12 : k0 / 12), kx = x0 + bxl - 2 + (hh ? k1 % 12 : k0 % 12);
+                bias[j][i] = (ky >= wy0 && ky < wy1 && kx >= wx0 && kx < wx1) ? 0.0f : -INFINITY;
+            }
+    }
+    // LDS byte offsets of this lane's operand rows: K fragment rows (key = 32 j + r), V^T transposing reads
+    int kofs[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int kk = 32 * j + r;
+        kofs[j] = ((kk / 12) * kAttHC + bxl + kk % 12) * kAmRow + hh * 16;
+    }
+    const int li = lane & 15, tq = li >> 2, tp = li & 3, g2 = (lane >> 4) & 1;
+    int vofs[3][2][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int wh = 0; wh < 2; ++wh) {
+                const int kk = 32 * j + 16 * s2 + 8 * wh + 4 * hh + tq;                 // acc-order key of element group `wh`, row tq of the 4-row block
+                vofs[j][s2][wh] = ((kk / 12) * kAttHC + bxl + kk % 12) * kAmRow + (16 * g2 + 4 * tp) * 2;
+            }
+
+#pragma unroll 1
+    for (int hg = 0; hg < 4; ++hg) {
+        Frag<bf16_t> qf[2];
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+            qf[hl].v = *reinterpret_cast<const bf16x8*>(Q + qtok * 128 + (2 * hg + hl) * 16 + 8 * hh);
+        {
+            raw16 kv[AmPlan::ITER], vv[AmPlan::ITER];
+            am_load(plan, K, hg, kv);
+            am_load(plan, Vv, hg, vv);
+            if (hg) __syncthreads();                                       // previous head pair fully consumed
+            am_store(plan, ldsK, kv);
+            am_store(plan, ldsV, vv);
+        }
+        __syncthreads();
+        // one accumulator per head: the V^T operand holds BOTH heads' 32 channels on its 32 rows, so each product
+        // also fills the other head's 16 rows with garbage -- simply never read (cheaper than masking the operand)
+        f32x16 o[2];
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+            f32x16 S[3];
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                Frag<bf16_t> kf;
+                kf.v = __builtin_bit_cast(bf16x8, load_raw16(ldsK + kofs[j] + hl * 32));
+                S[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, qf[hl].v, bias[j], 0, 0, 0);   // S^T[key, q] + mask bias
+#pragma unroll
+                for (int i = 0; i < 16; ++i) m = fmaxf(m, S[j][i]);
+            }
+            m = xhalf_max(m);
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { S[j][i] = fast_exp2(S[j][i] - m); sum += S[j][i]; }
+            const float inv = 1.0f / xhalf_sum(sum);                         // empty window (h < w quirk): NaN, as the reference
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[hl][i] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(ldsV + vofs[j][s2][0]));
+                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(ldsV + vofs[j][s2][1]));
+                    Frag<bf16_t> vf;
+                    vf.v = __builtin_bit_cast(bf16x8, (short __attribute__((ext_vector_type(8)))){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
+                    mma(vf, acc_to_frag(S[j], s2, bf16_t()), o[hl]);          // O^T[d, q] += V^T P^T
+                }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[hl][8 * hl + i] *= inv;           // rows 16 hl .. 16 hl + 15 are this head's
+        }
+        if (qok) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& oo = o[g >> 1];                                // pieces 0,1 (rows 0-15): head 0; pieces 2,3: head 1
+                store4(O + qtok * 128 + hg * 32 + 8 * g + 4 * hh, f32x4{oo[4 * g], oo[4 * g + 1], oo[4 * g + 2], oo[4 * g + 3]});
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
