@@ -121,7 +121,7 @@ WorkLayout work_layout(const Dims& d, int prec) {
 // Dynamic LDS sizes (bytes) and the opt-in above the 64 KiB default (a workgroup may use all 160 KiB of a CU).
 template <typename T> size_t lds_conv64(int w) { return WRing<T, kConv64Chunk>::LDS_BYTES + ConvIn<T>::bytes(w) + 4 * TileIO<2, T>::BYTES; }
 constexpr size_t kLdsParams = 1024;   // 256 LayerNorm floats
-template <typename T> size_t lds_spa1(int w) { return WRing<T, kSpaChunk>::LDS_BYTES + ConvIn<T>::bytes(w) + kLdsParams; }
+template <typename T, int CH = kSpaChunk> size_t lds_spa1(int w) { return WRing<T, CH>::LDS_BYTES + ConvIn<T>::bytes(w) + kLdsParams; }
 template <typename T> size_t lds_ring() { return WRing<T, kSpaChunk>::LDS_BYTES + kLdsParams; }
 template <typename T> size_t lds_spa2() { return WRing<T, kSpaChunk>::LDS_BYTES + kLdsParams + 4 * TileIO<4, T>::BYTES; }
 template <typename T> size_t lds_up() { return WRing<T, kUpChunk>::LDS_BYTES + 4 * TileIO<2, T>::BYTES; }
@@ -174,6 +174,24 @@ int run_pack(std::vector<PackOp>& ops, T* dst, int expect_frags, hipStream_t st)
         total += nf;
     }
     if (total != expect_frags) return fail(LFT_ERR_ARG, "internal: stream has %d fragments, expected %d", total, expect_frags);
+    return 0;
+}
+
+// k_spa1 launch with the ring chunk size that fits best: 16-fragment chunks if two workgroups then still share a CU
+// (<= 80 KiB each) or if they are the only ones fitting at all... else 8-fragment chunks (wide views, fp32).
+template <typename T, bool PE_ONLY>
+int launch_spa1(unsigned nwg, const T* in, const T* ws, const float* ln, const T* petok, T* tok, T* q, T* k, T* v, T* pe_out,
+                int nimg, const Dims& d, hipStream_t st) {
+    const size_t l16 = lds_spa1<T, 16>(d.w), l8 = lds_spa1<T, 8>(d.w);
+    const bool use8 = (l16 > 80 * 1024 && l8 <= 80 * 1024) || l16 > kMaxLds;
+    int rc;
+    if (use8) {
+        if ((rc = allow_lds(k_spa1<T, PE_ONLY, 8>, l8, "k_spa1"))) return rc;
+        k_spa1<T, PE_ONLY, 8><<<nwg, 256, l8, st>>>(in, ws, ln, petok, tok, q, k, v, pe_out, nimg, d.h, d.w);
+    } else {
+        if ((rc = allow_lds(k_spa1<T, PE_ONLY, 16>, l16, "k_spa1"))) return rc;
+        k_spa1<T, PE_ONLY, 16><<<nwg, 256, l16, st>>>(in, ws, ln, petok, tok, q, k, v, pe_out, nimg, d.h, d.w);
+    }
     return 0;
 }
 
@@ -232,10 +250,8 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
             if ((rc = run_pack<T>(ops, at<T>(packed, L.s_spa2[l]), kFragsSpa2, st))) return rc;
         }
         // embedded spatial position tokens of this layer (reference LFT.py:180), [h*w][128] in the activation type
-        if ((rc = allow_lds(k_spa1<T, true>, lds_spa1<T>(d.w), "k_spa1"))) return rc;
-        k_spa1<T, true><<<(d.hw + 127) / 128, 256, lds_spa1<T>(d.w), st>>>(
-            at<T>(packed, L.spa_pe_img), at<T>(packed, L.s_spa1[l]), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-            at<T>(packed, L.petok[l]), 1, d.h, d.w);
+        if ((rc = launch_spa1<T, true>((unsigned)((d.hw + 127) / 128), at<T>(packed, L.spa_pe_img), at<T>(packed, L.s_spa1[l]), nullptr, nullptr,
+                                       nullptr, nullptr, nullptr, nullptr, at<T>(packed, L.petok[l]), 1, d, st))) return rc;
         LFT_LAUNCH_OK("k_spa1<pe>");
     }
     {   // up-sampler: per 32-row chunk of the 1x1 conv, followed by the matching columns of the overlap-add matrix
@@ -311,9 +327,7 @@ int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, con
     T *tok = at<T>(ws, W.tok), *q = at<T>(ws, W.q), *k = at<T>(ws, W.k), *v = at<T>(ws, W.v), *o = at<T>(ws, W.o);
     const float* ln = at<float>(packed, L.ln_spa[l]);
     int rc;
-    if ((rc = allow_lds(k_spa1<T, false>, lds_spa1<T>(d.w), "k_spa1"))) return rc;
-    k_spa1<T, false><<<nwg, 256, lds_spa1<T>(d.w), st>>>(in, at<T>(packed, L.s_spa1[l]), ln, at<T>(packed, L.petok[l]),
-                                                         tok, q, k, v, nullptr, nimg, d.h, d.w);
+    if ((rc = launch_spa1<T, false>((unsigned)nwg, in, at<T>(packed, L.s_spa1[l]), ln, at<T>(packed, L.petok[l]), tok, q, k, v, nullptr, nimg, d, st))) return rc;
     LFT_LAUNCH_OK("k_spa1");
     if constexpr (sizeof(T) == 2) {
         const unsigned ntile = (unsigned)(nimg * ((d.h + kAttTY - 1) / kAttTY) * ((d.w + kAttTX - 1) / kAttTX));

@@ -17,7 +17,7 @@
 #endif
 constexpr int kUpChunk = LFT_UP_CHUNK;    // k_up uses few registers: a smaller ring lets more workgroups share a CU
 constexpr int kSpaChunk = 16;   // fragments per ring chunk: one conv tap (4 k-steps x 4 row tiles), half an in_proj matrix
-template <typename T, bool PE_ONLY>
+template <typename T, bool PE_ONLY, int CH = kSpaChunk>
 __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const T* __restrict__ petok,
                                               T* __restrict__ TOK, T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vv,
@@ -32,11 +32,11 @@ __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const 
     LFT_STAMP(0);
     typename RawPiece<T>::type pe_raw[16];                                    // position tokens of this lane's token, kept packed
     if (!PE_ONLY) load_lane_major_raw<4, T>(petok + (size_t)((p0 >> 5) + wave) * 4096, lane, pe_raw);   // early, 8 coalesced loads
-    char* lds_in = smem + WRing<T, kSpaChunk>::LDS_BYTES;
+    char* lds_in = smem + WRing<T, CH>::LDS_BYTES;
     float* lds_ln = reinterpret_cast<float*>(lds_in + ConvIn<T>::bytes(w));
     raw16 lnv = raw16{0u, 0u, 0u, 0u};
     if (!PE_ONLY) lnv = params_load(ln, 256);                         // norm.{weight,bias}; ln is null in the pack-time PE_ONLY launch
-    WRing<T, kSpaChunk> ring;
+    WRing<T, CH> ring;
     ring.init(ws, smem, PE_ONLY ? 144 : 240, p0 + 128 <= hw);
     stage_conv_input<T>(X + (size_t)im * hw * 64, p0, hw, w, lds_in);
     LFT_STAMP(12);
@@ -153,8 +153,10 @@ __global__ __launch_bounds__(256) void k_spa_attn(const T* __restrict__ Q, const
             for (int c = 0; c < 16; ++c) o[c] += pr * kv[c];
         }
     }
-    // empty window (only possible for h < w, see above): sum = 0 -> 0 * inf = NaN, as the reference's softmax of all -inf
-    const float inv = 1.0f / sum;
+    // empty window (only possible for h < w, see above): the reference run under torch >= 2.5 (the version that generated
+    // tests/golden) gives a ZERO attention output for a fully masked row ("safe softmax" in F.scaled_dot_product_attention);
+    // older torch gave NaN.  We follow the pinned behaviour: sum == 0 -> 0.
+    const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
         store4(O + tok * 128 + head * 16 + 4 * g, f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv});
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void k_spa_attn<bf16_t>(const bf16_t* __restri
             }
         }
     }
-    const float inv = 1.0f / sum;      // empty window -> NaN, see the generic kernel
+    const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;      // empty window -> 0, see the generic kernel
 #pragma unroll
     for (int g = 0; g < 4; ++g)
         store4(O + tok * 128 + head * 16 + 4 * g, f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv});
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(kAttThreads) void k_spa_attn_lds(const bf16_t* __re
     }
 #endif
     if (!valid) return;
-    const float inv = 1.0f / sum;          // empty window (h < w quirk): 0 * inf = NaN as in the reference
+    const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;      // empty window (h < w quirk) -> 0, see the generic kernel
 #pragma unroll
     for (int g = 0; g < 4; ++g)
         store4(O + tok * 128 + hg * 64 + hl * 16 + 4 * g, f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv});
@@ -500,13 +502,14 @@ __global__ __launch_bounds__(256, 2) void k_spa_attn_mfma(const bf16_t* __restri
 #pragma unroll
                 for (int i = 0; i < 16; ++i) m = fmaxf(m, S[j][i]);
             }
-            m = xhalf_max(m);
+            m = fmaxf(xhalf_max(m), -1.0e30f);                               // empty window: keep exp2(-inf - m) = 0, not NaN
             float sum = 0.0f;
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { S[j][i] = fast_exp2(S[j][i] - m); sum += S[j][i]; }
-            const float inv = 1.0f / xhalf_sum(sum);                         // empty window (h < w quirk): NaN, as the reference
+            sum = xhalf_sum(sum);
+            const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;                // empty window (h < w quirk): 0, as the pinned reference
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[hl][i] = 0.0f;
 #pragma unroll

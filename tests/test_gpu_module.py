@@ -12,7 +12,7 @@ from lft_amd.params import deterministic_state, synthetic_lr
 from oracle import lft_oracle as O
 
 pytestmark = pytest.mark.gpu
-GOLDEN = ["tiny_a5_s2_b2_6x6", "small_a5_s4_b1_8x8", "small_a9_s4_b1_8x8", "rect_a5_s2_b1_8x6", "cfg1_a5_s2_b1_32x32", "cfg2_a5_s4_b1_32x32"]
+GOLDEN = ["tiny_a5_s2_b2_6x6", "small_a5_s4_b1_8x8", "small_a9_s4_b1_8x8", "rect_a5_s2_b1_8x6", "wide_a2_s2_b1_6x12", "cfg1_a5_s2_b1_32x32", "cfg2_a5_s4_b1_32x32"]
 
 
 def make_net(A, s, wseed, flavor, precision):

@@ -66,7 +66,9 @@ def test_bicubic(A, h, w, s):
     assert (out.cpu() - ref).abs().max() <= 2e-6, G.err_report(out.cpu(), ref)
 
 
-CASES = [(5, 2, 2, 6, 6), (5, 4, 1, 8, 8), (3, 2, 1, 9, 7), (5, 2, 1, 32, 32), (9, 4, 1, 8, 8), (6, 2, 1, 6, 5)]   # 81 views: 3 column tiles; 36: 2
+CASES = [(5, 2, 2, 6, 6), (5, 4, 1, 8, 8), (3, 2, 1, 9, 7), (5, 2, 1, 32, 32), (9, 4, 1, 8, 8), (6, 2, 1, 6, 5),   # 81 views: 3 column tiles; 36: 2
+         (2, 2, 1, 64, 64),                   # 64-wide views: two column tiles per row, wide-tile LDS path
+         (2, 2, 1, 6, 12), (2, 2, 1, 36, 64)]  # h < w: queries with x - 2 >= h have an EMPTY window (LFT.py:155) -> attention output 0
 
 
 @pytest.fixture(scope="module", params=CASES, ids=lambda c: "A%d_s%d_B%d_%dx%d" % c)

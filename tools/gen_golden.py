@@ -136,12 +136,18 @@ def main():
     torch.set_num_threads(8)
     ref = load_reference()
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    if "--wide-only" in sys.argv:      # add the h < w fixture without rewriting the others
+        run_case(ref, "wide_a2_s2_b1_6x12", 2, 2, 1, 6, 12, full_taps=True)
+        return
     misc(ref)
     tiling(load_reference_tiling())
     run_case(ref, "tiny_a5_s2_b2_6x6", 5, 2, 2, 6, 6, full_taps=True)       # per-stage activations in full
     run_case(ref, "small_a5_s4_b1_8x8", 5, 4, 1, 8, 8)
     run_case(ref, "small_a9_s4_b1_8x8", 9, 4, 1, 8, 8)
     run_case(ref, "rect_a5_s2_b1_8x6", 5, 2, 1, 8, 6)                       # h > w: still the correct window rule
+    # h < w: LFT.py:155 clamps the window's column range with h, so queries with x - 2 >= h have an EMPTY window; under the
+    # torch that runs here (>= 2.5) F.scaled_dot_product_attention returns 0 for those rows (older torch: NaN)
+    run_case(ref, "wide_a2_s2_b1_6x12", 2, 2, 1, 6, 12, full_taps=True)
     run_case(ref, "cfg1_a5_s2_b1_32x32", 5, 2, 1, 32, 32, flavor="default")   # BASELINE configs[0]
     run_case(ref, "cfg2_a5_s4_b1_32x32", 5, 4, 1, 32, 32, flavor="default")   # one patch of configs[1]
 
