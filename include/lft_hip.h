@@ -92,6 +92,30 @@ int lft_scene_counts(int h0, int w0, int patch, int stride, int* num_u, int* num
 int lft_scene_divide(const float* scene, float* patches, int A, int h0, int w0, int patch, int stride, void* stream);
 int lft_scene_integrate(const float* sr_patches, float* sr_scene, int A, int h0, int w0, int patch, int stride, int s, void* stream);
 
+/* ---- fp32 training step (what PyTorch autograd records / replays for reference LFT.py:52-83 under train.py:89-107) ----
+ * The 78 parameters are read IN PLACE (device pointers in state_dict order, HOST array), nothing is packed.
+ * `tape` (lft_train_tape_bytes) holds every activation the backward pass re-reads plus its scratch; it must stay
+ * untouched between lft_train_forward and lft_train_backward of the same step.
+ * lft_train_forward : lr [B,1,A*h,A*w] -> out [B,1,A*h*s,A*w*s] (same function as lft_forward, unfused fp32 kernels).
+ * lft_train_backward: dout [B,1,A*h*s,A*w*s] -> grads = ONE flat fp32 buffer (lft_train_grad_floats) holding the 78
+ *                     parameter gradients back to back in state_dict order, fully overwritten (not accumulated).
+ *                     A data-parallel job all-reduces this one buffer.  No gradient flows to lr.
+ * lft_train_tape_offset: float offset of a saved activation inside the tape, for tests ("feat", "ang0.y", "spa2.tok", ...). */
+int lft_train_tape_bytes(int B, int A, int h, int w, int s, size_t* out_bytes);
+int lft_train_grad_floats(int s, size_t* out_floats);
+int lft_train_tape_offset(const char* name, int B, int A, int h, int w, int s, size_t* out_float_offset);
+int lft_train_forward(const float* const* params, int nparams, const float* lr, float* out, void* tape,
+                      int B, int A, int h, int w, int s, void* stream);
+int lft_train_backward(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
+                       int B, int A, int h, int w, int s, void* stream);
+/* get_loss (reference LFT.py:269-277, torch.nn.L1Loss): *loss = mean |sr - hr|; if dsr != NULL also
+ * dsr = gscale * sign(sr - hr) (gscale = 1/n for d loss / d sr).  scratch1024: 1024 floats of device scratch. */
+int lft_l1_loss(const float* sr, const float* hr, long long n, float* dsr, float gscale, float* loss, float* scratch1024, void* stream);
+/* torch.optim.Adam step (train.py:77-83: betas (0.9, 0.999), eps 1e-8, weight_decay 0) on one flat fp32 buffer;
+ * step counts from 1; the gradient is multiplied by gscale first (1/world_size after a sum all-reduce). */
+int lft_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                  int step, float gscale, void* stream);
+
 /* Debug aid: a single conv_init[which] launch (with_res: add `res`; extra_lds: pad the LDS request). */
 int lft_debug_conv64(const void* packed, int which, int with_res, const void* in, const void* res, void* out,
                      int B, int A, int h, int w, int s, int prec, int extra_lds, void* stream);

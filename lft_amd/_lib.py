@@ -8,12 +8,12 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LFT_LIB_PATH") or os.path.join(HERE, "liblft_hip.so")   # LFT_LIB_PATH: experiment builds (tools/ab_build.py)
-SOURCES = ["lft_api.hip", "lft_common.cuh", "lft_kernels_a.cuh", "lft_kernels_b.cuh"]
+SOURCES = ["lft_api.hip", "lft_common.cuh", "lft_kernels_a.cuh", "lft_kernels_b.cuh", "lft_train.cuh", "lft_train_host.cuh"]
 
 PREC_F32, PREC_BF16 = 0, 1
 NUM_PARAMS = 78
@@ -65,6 +65,13 @@ _SIGS = {
     "lft_scene_counts": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "lft_scene_divide": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lft_scene_integrate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_train_tape_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "lft_train_grad_floats": (c_int, [c_int, POINTER(c_size_t)]),
+    "lft_train_tape_offset": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "lft_train_forward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_train_backward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_l1_loss": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "lft_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
     "lft_debug_conv64": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lft_mfma_selftest": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
 }

@@ -6,6 +6,8 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
+#include <string>
 #include <algorithm>
 #include <utility>
 #include <vector>
@@ -380,6 +382,8 @@ int forward_impl(const void* packed, const float* lr, float* out, void* ws, cons
     return upsample<T>(packed, L, xb, lr, out, ws, W, d, st);
 }
 
+#include "lft_train_host.cuh"
+
 }  // namespace
 
 // ================================================================================ C ABI
@@ -590,6 +594,86 @@ int lft_mfma_selftest(const float* Am, const float* Bm, const float* W2, float* 
     else if (prec == LFT_PREC_BF16) k_selftest<bf16_t><<<1, 64, 0, st>>>(Am, Bm, W2, C, D);
     else return fail(LFT_ERR_ARG, "bad prec %d", prec);
     LFT_LAUNCH_OK("k_selftest");
+    return 0;
+}
+
+// ================================================================================ training (fp32)
+int lft_train_tape_bytes(int B, int A, int h, int w, int s, size_t* out_bytes) {
+    Dims d; int rc;
+    if (!out_bytes) return fail(LFT_ERR_ARG, "out_bytes is null");
+    if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
+    *out_bytes = train_layout(d).total * sizeof(float);
+    return 0;
+}
+int lft_train_grad_floats(int s, size_t* out_floats) {
+    if (!out_floats) return fail(LFT_ERR_ARG, "out_floats is null");
+    if (s != 2 && s != 4) return fail(LFT_ERR_SHAPE, "scale factor must be 2 or 4, got %d", s);
+    *out_floats = (size_t)param_info(s).total;
+    return 0;
+}
+int lft_train_tape_offset(const char* name, int B, int A, int h, int w, int s, size_t* out_float_offset) {
+    Dims d; int rc;
+    if (!name || !out_float_offset) return fail(LFT_ERR_ARG, "null pointer");
+    if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
+    const TrainLayout T = train_layout(d);
+    const std::string n(name);
+    auto layer = [&](char c) { return c - '0'; };
+    if (n == "x0") *out_float_offset = T.x0; else if (n == "feat") *out_float_offset = T.feat;
+    else if (n == "c1") *out_float_offset = T.c1; else if (n == "c2") *out_float_offset = T.c2; else if (n == "c3") *out_float_offset = T.c3;
+    else if (n == "body") *out_float_offset = T.body; else if (n == "act") *out_float_offset = T.act;
+    else if (n == "skip") *out_float_offset = T.skip;
+    else if (n.size() > 5 && n.compare(0, 3, "ang") == 0 && n[3] >= '0' && n[3] < '0' + kLayers && n[4] == '.') {
+        const AngTape& a = T.ang[layer(n[3])];
+        const std::string f = n.substr(5);
+        if (f == "n") *out_float_offset = a.n; else if (f == "qk") *out_float_offset = a.qk; else if (f == "v") *out_float_offset = a.v;
+        else if (f == "o") *out_float_offset = a.o; else if (f == "t1") *out_float_offset = a.t1; else if (f == "m") *out_float_offset = a.m;
+        else if (f == "hdn") *out_float_offset = a.hdn; else if (f == "y") *out_float_offset = a.y;
+        else return fail(LFT_ERR_ARG, "unknown tape field %s", name);
+    } else if (n.size() > 5 && n.compare(0, 3, "spa") == 0 && n[3] >= '0' && n[3] < '0' + kLayers && n[4] == '.') {
+        const SpaTape& a = T.spa[layer(n[3])];
+        const std::string f = n.substr(5);
+        if (f == "tok") *out_float_offset = a.tok; else if (f == "n") *out_float_offset = a.n; else if (f == "q") *out_float_offset = a.q;
+        else if (f == "k") *out_float_offset = a.k; else if (f == "v") *out_float_offset = a.v; else if (f == "o") *out_float_offset = a.o;
+        else if (f == "t1") *out_float_offset = a.t1; else if (f == "m") *out_float_offset = a.m; else if (f == "hdn") *out_float_offset = a.hdn;
+        else if (f == "t2") *out_float_offset = a.t2; else if (f == "y") *out_float_offset = a.y; else if (f == "petok") *out_float_offset = a.petok;
+        else return fail(LFT_ERR_ARG, "unknown tape field %s", name);
+    } else return fail(LFT_ERR_ARG, "unknown tape field %s", name);
+    return 0;
+}
+int lft_train_forward(const float* const* params, int nparams, const float* lr, float* out, void* tape,
+                      int B, int A, int h, int w, int s, void* stream) {
+    Dims d; int rc;
+    if (!params || !lr || !out || !tape) return fail(LFT_ERR_ARG, "null pointer");
+    if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
+    for (int i = 0; i < nparams; ++i) if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
+    if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
+    return train_forward(params, lr, out, static_cast<float*>(tape), d, static_cast<hipStream_t>(stream));
+}
+int lft_train_backward(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
+                       int B, int A, int h, int w, int s, void* stream) {
+    Dims d; int rc;
+    if (!params || !lr || !tape || !dout || !grads) return fail(LFT_ERR_ARG, "null pointer");
+    if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
+    for (int i = 0; i < nparams; ++i) if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
+    if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
+    return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, static_cast<hipStream_t>(stream));
+}
+int lft_l1_loss(const float* sr, const float* hr, long long n, float* dsr, float gscale, float* loss, float* scratch1024, void* stream) {
+    if (!sr || !hr || !loss || !scratch1024 || n < 1) return fail(LFT_ERR_ARG, "bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nb = (int)std::min<long long>(1024, (n + 255) / 256);
+    k_l1_partial<<<nb, 256, 0, st>>>(sr, hr, dsr, gscale, n, scratch1024);
+    LFT_LAUNCH_OK("k_l1_partial");
+    k_l1_final<<<1, 64, 0, st>>>(scratch1024, nb, 1.0f / (float)n, loss);
+    LFT_LAUNCH_OK("k_l1_final");
+    return 0;
+}
+int lft_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                  int step, float gscale, void* stream) {
+    if (!p || !g || !m || !v || n < 1 || step < 1) return fail(LFT_ERR_ARG, "bad argument");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    k_adam<<<blocks_for(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2, gscale);
+    LFT_LAUNCH_OK("k_adam");
     return 0;
 }
 

@@ -1,0 +1,666 @@
+// lft_train.cuh -- fp32 training kernels (forward with a saved-activation tape + backward) for the LFT network.
+//
+// The reference trains in fp32 through PyTorch autograd (train.py:74-107: net(data) -> L1Loss -> loss.backward() ->
+// Adam).  This file is the MI355X counterpart of what autograd records and replays for model/LFT.py:52-83:
+// every linear map of the network as an exact-fp32 MFMA product in the "token on lane" layout of lft_common.cuh,
+//   k_lin    Y = act(X W^T) (+R)        any of the network's Linear / 1x1 / 3x3-per-view convolutions, and -- with
+//                                       transposed weight strides and flipped taps -- their input gradients
+//   k_wgrad  dW = dY^T X                split over token chunks (deterministic two-stage reduction)
+// plus the small VALU kernels around them (LayerNorm, both attentions, activations, up-sampler tail).
+// Weights are read in place from the 78 parameter tensors (they change every step, so nothing is packed).
+// All tensors are fp32 channels-last [token][channel]; token = ((b*V + v)*h + y)*w + x.
+#pragma once
+#include "lft_common.cuh"
+
+// ------------------------------------------------------------------------------------------
+// Generic linear / per-view 3x3 convolution on MFMA.
+//   Y[t][o] = act( sum_tap sum_i W[o*so + i*si + tap*st] * X[shift_tap(t)][i] ) (+ R[t][o])
+// taps == 1: plain Linear.  taps == 9: tap -> (dy, dx) = (tap/3 - 1, tap%3 - 1), the source token is
+// (y + dy, x + dx) of the same view image (zero outside: per-view zero padding, reference LFT.py:24,28,167);
+// flip negates the offset, which together with swapped so/si turns the kernel into the convolution's input gradient.
+// A wave owns 32 tokens x NT*32 output channels (blockIdx.y selects the channel group).
+// ------------------------------------------------------------------------------------------
+struct LinP {
+    const float* X; int ldx;
+    const float* W; int so, si, st;
+    const float* R; int ldr;          // optional: accumulator initialised with R (residual, or Y itself to accumulate)
+    float* Y; int ldy;
+    int Ci, Co, taps, flip, act;      // act: 0 none, 1 relu, 2 leaky relu 0.2
+    int h, w;
+    long long N;
+};
+
+template <bool CONTIG>
+LFT_DEV Frag<float> load_w_frag(const float* __restrict__ W, int o, int k, int so, int si, int base) {
+    Frag<float> f;
+    if constexpr (CONTIG) {                 // si == 1 and 16-byte aligned rows: two dwordx4
+        const float* p = W + (size_t)o * so + base + k;
+        f.lo = load4(p); f.hi = load4(p + 4);
+    } else {
+        const float* p = W + (size_t)o * so + base + (size_t)k * si;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f.lo[j] = p[(size_t)j * si]; f.hi[j] = p[(size_t)(j + 4) * si]; }
+    }
+    return f;
+}
+
+template <int NT, bool CONTIG>
+__global__ __launch_bounds__(256) void k_lin(const LinP p) {
+    __shared__ __attribute__((aligned(16))) char scr_all[4 * TileIO<NT, float>::BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, kh = lane >> 5;
+    char* scr = scr_all + wave * TileIO<NT, float>::BYTES;
+    const long long t0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    if (t0 >= p.N) return;
+    const int nvalid = (int)min((long long)32, p.N - t0);
+    const int o0 = blockIdx.y * NT * 32;
+    const long long t = min(t0 + r, p.N - 1);
+    const int hw = p.h * p.w;
+    const int pix = (int)(t % hw), y = pix / p.w, x = pix - y * p.w;
+    f32x16 acc[NT];
+    if (p.R) load_tile<NT, float>(p.R + t0 * p.ldr + o0, nvalid, lane, acc, scr, (size_t)p.ldr * 4);
+    else zero_acc<NT>(acc);
+    for (int tap = 0; tap < p.taps; ++tap) {
+        int dy = 0, dx = 0;
+        if (p.taps == 9) { dy = tap / 3 - 1; dx = tap % 3 - 1; if (p.flip) { dy = -dy; dx = -dx; } }
+        const bool ok = (t0 + r < p.N) && (y + dy >= 0) && (y + dy < p.h) && (x + dx >= 0) && (x + dx < p.w);
+        const float* row = p.X + (ok ? (t + dy * p.w + dx) : t) * p.ldx + 8 * kh;
+        for (int k0 = 0; k0 < p.Ci; k0 += 16) {
+            const Frag<float> b = load_row8(row + k0, ok, 0.0f);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const Frag<float> a = load_w_frag<CONTIG>(p.W, o0 + 32 * nt + r, k0 + 8 * kh, p.so, p.si, tap * p.st);
+                mma(a, b, acc[nt]);
+            }
+        }
+    }
+    if (p.act) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = acc[nt][i];
+                acc[nt][i] = v > 0.0f ? v : (p.act == 1 ? 0.0f : 0.2f * v);
+            }
+    }
+    store_tile<NT, float>(p.Y + t0 * p.ldy + o0, nvalid, lane, acc, scr, (size_t)p.ldy * 4);
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient: part[chunk][o*so + i*si + tap*st] = sum_{t in chunk} dY[t][o] * X[shift_tap(t)][i]
+// MFMA with k = token: A[m = o][k] = dY[t0 + k][o], B[k][n = i] = X[shift(t0 + k)][i]; both operands are read
+// straight from the channels-last tensors (lanes = consecutive channels of one token: 128-byte segments).
+// A wave owns one 32-row block of dY channels, one tap, NI 32-column blocks of X channels and one token chunk.
+// grid: x = chunk, y = (o tile, i group), z = tap.   k_reduce then sums the chunks in a fixed order.
+// ------------------------------------------------------------------------------------------
+struct WgP {
+    const float* dY; int ldy;
+    const float* X; int ldx;
+    float* part; long long wsize;     // floats per chunk image of the weight
+    int so, si, st;
+    int Co, Ci, taps;
+    int h, w;
+    long long N, chunk_len;           // chunk_len % 16 == 0
+    int igroups;
+};
+
+template <int NI>
+__global__ __launch_bounds__(64) void k_wgrad(const WgP p) {
+    const int lane = threadIdx.x, r = lane & 31, kh = lane >> 5;
+    const int ot = blockIdx.y / p.igroups, ig = blockIdx.y % p.igroups, tap = blockIdx.z;
+    const int o0 = ot * 32, i0 = ig * NI * 32;
+    const long long ta = (long long)blockIdx.x * p.chunk_len, tb = min(ta + p.chunk_len, p.N);
+    const int hw = p.h * p.w;
+    int dy = 0, dx = 0;
+    if (p.taps == 9) { dy = tap / 3 - 1; dx = tap % 3 - 1; }
+    f32x16 acc[NI];
+    zero_acc<NI>(acc);
+    for (long long t0 = ta; t0 < tb; t0 += 16) {
+        Frag<float> a, b[NI];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long t = t0 + 8 * kh + j;
+            const bool in = t < tb;
+            const long long tc = in ? t : ta;
+            const int pix = (int)(tc % hw), y = pix / p.w, x = pix - y * p.w;
+            const bool ok = in && (y + dy >= 0) && (y + dy < p.h) && (x + dx >= 0) && (x + dx < p.w);
+            const float av = p.dY[tc * p.ldy + o0 + r];
+            const float* xr = p.X + (ok ? tc + dy * p.w + dx : tc) * p.ldx + i0 + r;
+            if (j < 4) a.lo[j] = in ? av : 0.0f; else a.hi[j - 4] = in ? av : 0.0f;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const float bv = xr[32 * ni];
+                if (j < 4) b[ni].lo[j] = ok ? bv : 0.0f; else b[ni].hi[j - 4] = ok ? bv : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) mma(a, b[ni], acc[ni]);
+    }
+    float* dst = p.part + (long long)blockIdx.x * p.wsize + (size_t)tap * p.st;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            dst[(size_t)(o0 + acc_row(i, kh)) * p.so + (size_t)(i0 + 32 * ni + r) * p.si] = acc[ni][i];
+}
+
+// dst[i] (+)= sum_c part[c][i], chunks summed in index order (deterministic).
+__global__ void k_reduce(const float* __restrict__ part, int nch, long long n, long long stride, float* __restrict__ dst, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int c = 0; c < nch; ++c) s += part[(long long)c * stride + i];
+    dst[i] = accumulate ? dst[i] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Plain position tables (reference LFT.py:86-115): angular [V][64], spatial [h*w][64].
+// ------------------------------------------------------------------------------------------
+__global__ void k_pe_plain(float* __restrict__ ang, float* __restrict__ spa, int V, int h, int w) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < V * 64) ang[idx] = pe_value(idx >> 6, idx & 63);
+    if (idx < h * w * 64) {
+        const int pp = idx >> 6, c = idx & 63;
+        spa[idx] = (pe_value(pp / w, c) + pe_value(pp % w, c)) / 2.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over C channels (C = 64 or 128), input u = X (+ pe): pe_mode 0 none, 1 angular pe[v][c] with
+// v = (t / hw) % V, 2 spatial-token pe[t % hw][c].  16 lanes per token, C/16 channels per lane.
+// Backward: du = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dY * gamma; out = (add ? add : 0) + du;
+// per-block partial sums of dgamma = sum dY * xhat and dbeta = sum dY go to pgb[block][2C].
+// ------------------------------------------------------------------------------------------
+template <int C>
+LFT_DEV void ln_load(const float* __restrict__ X, const float* __restrict__ pe, int pe_mode, long long t, int hw, int V, int sub,
+                     float (&u)[C / 16]) {
+    constexpr int PER = C / 16;
+    const float* row = X + t * C + sub * PER;
+#pragma unroll
+    for (int g = 0; g < PER / 4; ++g) {
+        const f32x4 v = load4(row + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[4 * g + j] = v[j];
+    }
+    if (pe_mode) {
+        const long long prow = pe_mode == 1 ? (t / hw) % V : t % hw;
+        const float* pr = pe + prow * C + sub * PER;
+#pragma unroll
+        for (int g = 0; g < PER / 4; ++g) {
+            const f32x4 v = load4(pr + 4 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[4 * g + j] += v[j];
+        }
+    }
+}
+LFT_DEV float sum16(float v) {
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+    return v;
+}
+template <int C>
+LFT_DEV void ln_stats(const float (&u)[C / 16], float& mean, float& rstd) {
+    constexpr int PER = C / 16;
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += u[i];
+    mean = sum16(s) * (1.0f / C);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const float d = u[i] - mean; q += d * d; }
+    rstd = 1.0f / sqrtf(sum16(q) * (1.0f / C) + LFT_LN_EPS);
+}
+template <int C>
+__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ X, const float* __restrict__ pe, int pe_mode,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                float* __restrict__ Y, long long N, int hw, int V) {
+    constexpr int PER = C / 16;
+    const int sub = threadIdx.x & 15;
+    const long long t = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long long tc = min(t, N - 1);
+    float u[PER], mean, rstd;
+    ln_load<C>(X, pe, pe_mode, tc, hw, V, sub, u);
+    ln_stats<C>(u, mean, rstd);
+    if (t >= N) return;
+#pragma unroll
+    for (int g = 0; g < PER / 4; ++g) {
+        const f32x4 gm = load4(gamma + sub * PER + 4 * g), bt = load4(beta + sub * PER + 4 * g);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (u[4 * g + j] - mean) * rstd * gm[j] + bt[j];
+        store4(Y + t * C + sub * PER + 4 * g, o);
+    }
+}
+template <int C>
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ X, const float* __restrict__ pe, int pe_mode,
+                                                const float* __restrict__ gamma, const float* dY,
+                                                const float* add, float* out,      // out may alias add or dY (same element, same thread)
+                                                float* __restrict__ pgb, long long N, int hw, int V) {
+    constexpr int PER = C / 16;
+    __shared__ float red[16][2 * C];
+    const int sub = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    float gm[PER], dg[PER], db[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { gm[i] = gamma[sub * PER + i]; dg[i] = 0.0f; db[i] = 0.0f; }
+    // the 16 lanes of a token share t, so the sum16 exchanges always see a full group
+    for (long long t = (long long)blockIdx.x * 16 + slot; t < N; t += (long long)gridDim.x * 16) {
+        float u[PER], mean, rstd, g[PER], xh[PER], dyv[PER];
+        ln_load<C>(X, pe, pe_mode, t, hw, V, sub, u);
+        ln_stats<C>(u, mean, rstd);
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int gq = 0; gq < PER / 4; ++gq) {
+            const f32x4 d = load4(dY + t * C + sub * PER + 4 * gq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dyv[4 * gq + j] = d[j];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            xh[i] = (u[i] - mean) * rstd;
+            g[i] = dyv[i] * gm[i];
+            s1 += g[i]; s2 += g[i] * xh[i];
+            dg[i] += dyv[i] * xh[i]; db[i] += dyv[i];
+        }
+        s1 = sum16(s1) * (1.0f / C); s2 = sum16(s2) * (1.0f / C);
+#pragma unroll
+        for (int gq = 0; gq < PER / 4; ++gq) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rstd * (g[4 * gq + j] - s1 - xh[4 * gq + j] * s2);
+            if (add) {
+                const f32x4 a = load4(add + t * C + sub * PER + 4 * gq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += a[j];
+            }
+            store4(out + t * C + sub * PER + 4 * gq, o);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { red[slot][sub * PER + i] = dg[i]; red[slot][C + sub * PER + i] = db[i]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[q][i];
+        pgb[(size_t)blockIdx.x * 2 * C + i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Elementwise helpers.
+// ------------------------------------------------------------------------------------------
+// out = g * act'(y): relu (mode 1): y > 0; leaky relu 0.2 (mode 2): y > 0 ? 1 : 0.2  (y = act(z) has the sign of z)
+__global__ void k_act_bwd(const float* g, const float* __restrict__ y, float* out, long long n4, int mode) {   // out may alias g
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 gv = load4(g + 4 * i), yv = load4(y + 4 * i);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = yv[j] > 0.0f ? gv[j] : (mode == 1 ? 0.0f : 0.2f * gv[j]);
+    store4(out + 4 * i, o);
+}
+__global__ void k_add(float* __restrict__ a, const float* __restrict__ b, long long n4) {       // a += b
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 av = load4(a + 4 * i), bv = load4(b + 4 * i);
+    store4(a + 4 * i, f32x4{av[0] + bv[0], av[1] + bv[1], av[2] + bv[2], av[3] + bv[3]});
+}
+// out[i] = sum_img src[img][i], i < n (n = hw * C): gradient of the broadcast position tokens
+__global__ void k_sum_images(const float* __restrict__ src, int nimg, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int im = 0; im < nimg; ++im) s += src[(long long)im * n + i];
+    out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Angular attention (reference LFT.py:230-233): per pixel, sequence = the V views, 8 heads x 8 channels, no mask.
+// QK [N][128] (Q | K), Vv / O [N][64].  One workgroup per pixel (b, p); thread = (head, view), VP = padded views.
+// Backward is the usual two-pass form: per query (m, 1/l, D = sum_j P dP) and dQ; then per key dK, dV.
+// ------------------------------------------------------------------------------------------
+LFT_DEV void load8(const float* p, float (&o)[8]) {
+    const f32x4 a = load4(p), b = load4(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = b[j]; }
+}
+LFT_DEV void store8(float* p, const float (&o)[8]) {
+    store4(p, f32x4{o[0], o[1], o[2], o[3]});
+    store4(p + 4, f32x4{o[4], o[5], o[6], o[7]});
+}
+LFT_DEV float dot8(const float (&a)[8], const float* b) {
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s += a[c] * b[c];
+    return s;
+}
+template <int VP, bool BWD>
+__global__ __launch_bounds__(8 * VP) void k_ang_attn(const float* __restrict__ QK, const float* __restrict__ Vv,
+                                                     float* __restrict__ O, const float* __restrict__ dO,
+                                                     float* __restrict__ dQK, float* __restrict__ dV, int V, int hw) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Ks = sm;                         // [8][VP][8]
+    float* Vs = Ks + 8 * VP * 8;
+    float* Qs = Vs + 8 * VP * 8;            // BWD only
+    float* Ds = Qs + 8 * VP * 8;            // BWD only: dO
+    float* St = Ds + 8 * VP * 8;            // BWD only: [8][VP][3] = m, 1/l, D
+    const int hd = threadIdx.x / VP, i = threadIdx.x % VP;
+    const int b = blockIdx.x / hw, pix = blockIdx.x % hw;
+    const bool act = i < V;
+    const long long row = ((long long)b * V + min(i, V - 1)) * hw + pix;
+    const float scale = 0.35355339059327373f;            // 1 / sqrt(8)
+    float q[8], tmp[8], dov[8];
+    load8(QK + row * 128 + hd * 8, q);
+    load8(QK + row * 128 + 64 + hd * 8, tmp);
+    store8(Ks + (hd * VP + i) * 8, tmp);
+    load8(Vv + row * 64 + hd * 8, tmp);
+    store8(Vs + (hd * VP + i) * 8, tmp);
+    if (BWD) {
+        store8(Qs + (hd * VP + i) * 8, q);
+        load8(dO + row * 64 + hd * 8, dov);
+        store8(Ds + (hd * VP + i) * 8, dov);
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = 0; j < V; ++j) m = fmaxf(m, scale * dot8(q, Ks + (hd * VP + j) * 8));
+    float l = 0.0f;
+    if (!BWD) {
+        float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < V; ++j) {
+            const float pj = expf(scale * dot8(q, Ks + (hd * VP + j) * 8) - m);
+            l += pj;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] += pj * Vs[(hd * VP + j) * 8 + c];
+        }
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] *= inv;
+        if (act) store8(O + row * 64 + hd * 8, o);
+        return;
+    }
+    // ---- backward, pass A (per query) ----
+    float D = 0.0f, av[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < V; ++j) {
+        const float* kj = Ks + (hd * VP + j) * 8;
+        const float pj = expf(scale * dot8(q, kj) - m);
+        const float dp = dot8(dov, Vs + (hd * VP + j) * 8);
+        l += pj; D += pj * dp;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { av[c] += pj * dp * kj[c]; bv[c] += pj * kj[c]; }
+    }
+    const float inv = 1.0f / l;
+    D *= inv;
+    float dq[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dq[c] = scale * inv * (av[c] - D * bv[c]);
+    if (act) store8(dQK + row * 128 + hd * 8, dq);
+    St[(hd * VP + i) * 3 + 0] = m; St[(hd * VP + i) * 3 + 1] = inv; St[(hd * VP + i) * 3 + 2] = D;
+    __syncthreads();
+    // ---- pass B (per key j = this thread's view) ----
+    float kj[8], vj[8], dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { kj[c] = Ks[(hd * VP + i) * 8 + c]; vj[c] = Vs[(hd * VP + i) * 8 + c]; }
+    for (int qi = 0; qi < V; ++qi) {
+        const float* qq = Qs + (hd * VP + qi) * 8;
+        const float* dd = Ds + (hd * VP + qi) * 8;
+        const float pij = expf(scale * dot8(kj, qq) - St[(hd * VP + qi) * 3]) * St[(hd * VP + qi) * 3 + 1];
+        const float ds = pij * (dot8(vj, dd) - St[(hd * VP + qi) * 3 + 2]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { dk[c] += ds * qq[c]; dv[c] += pij * dd[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dk[c] *= scale;
+    if (act) {
+        store8(dQK + row * 128 + 64 + hd * 8, dk);
+        store8(dV + row * 64 + hd * 8, dv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Spatial windowed attention (reference LFT.py:147-162,183-187): 8 heads x 16, clamped 5x5 window with the
+// reference's min(h, x+3) column bound; a query with an empty window (h < w) outputs 0 and passes no gradient.
+// Q, K, Vv, O: [N][128].  Thread = (token, head).
+//   MODE 0: forward.   MODE 1: backward pass A (dQ and per-(token, head) stats m, 1/l, D).
+//   MODE 2: backward pass B, gather form: key j collects from the <= 25 queries i = j - (dy, dx) that see it.
+// ------------------------------------------------------------------------------------------
+LFT_DEV float dot16(const float (&a)[16], const float (&b)[16]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s += a[c] * b[c];
+    return s;
+}
+LFT_DEV void ld16(const float* p, float (&o)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = load4(p + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[4 * g + j] = v[j];
+    }
+}
+LFT_DEV void st16(float* p, const float (&o)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) store4(p + 4 * g, f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]});
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_win_attn(const float* __restrict__ Q, const float* __restrict__ K,
+                                                  const float* __restrict__ Vv, float* __restrict__ O,
+                                                  const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ dK,
+                                                  float* __restrict__ dV, float* __restrict__ stats, long long ntok, int h, int w) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long tok = idx >> 3;
+    const int head = (int)(idx & 7);
+    if (tok >= ntok) return;
+    const int hw = h * w;
+    const int pix = (int)(tok % hw);
+    const long long img0 = tok - pix;
+    const int y = pix / w, x = pix % w;
+    const float scale = 0.25f;                          // 1 / sqrt(16)
+    const size_t off = (size_t)tok * 128 + head * 16;
+    if (MODE == 0 || MODE == 1) {
+        const int y0 = max(0, y - 2), y1 = min(h, y + 3), x0 = max(0, x - 2), x1 = min(min(h, x + 3), w);   // LFT.py:150-160 (sic)
+        float q[16], kv[16], vv[16], dov[16];
+        ld16(Q + off, q);
+        if (MODE == 1) ld16(dO + off, dov);
+        float m = -INFINITY;
+        for (int ky = y0; ky < y1; ++ky)
+            for (int kx = x0; kx < x1; ++kx) {
+                ld16(K + (size_t)(img0 + ky * w + kx) * 128 + head * 16, kv);
+                m = fmaxf(m, scale * dot16(q, kv));
+            }
+        float l = 0.0f, D = 0.0f, o[16], a2[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { o[c] = 0.0f; a2[c] = 0.0f; }
+        for (int ky = y0; ky < y1; ++ky)
+            for (int kx = x0; kx < x1; ++kx) {
+                const size_t ko = (size_t)(img0 + ky * w + kx) * 128 + head * 16;
+                ld16(K + ko, kv);
+                ld16(Vv + ko, vv);
+                const float pj = expf(scale * dot16(q, kv) - m);
+                l += pj;
+                if (MODE == 0) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) o[c] += pj * vv[c];
+                } else {
+                    const float dp = dot16(dov, vv);
+                    D += pj * dp;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) { o[c] += pj * dp * kv[c]; a2[c] += pj * kv[c]; }
+                }
+            }
+        const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+        if (MODE == 0) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) o[c] *= inv;
+            st16(O + off, o);
+        } else {
+            D *= inv;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) o[c] = scale * inv * (o[c] - D * a2[c]);
+            st16(dQ + off, o);
+            float* s3 = stats + ((size_t)tok * 8 + head) * 3;
+            s3[0] = l > 0.0f ? m : 0.0f; s3[1] = inv; s3[2] = D;
+        }
+    } else {
+        float kj[16], vj[16], qi[16], di[16], dk[16], dv[16];
+        ld16(K + off, kj);
+        ld16(Vv + off, vj);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { dk[c] = 0.0f; dv[c] = 0.0f; }
+        if (x < h) {                                       // keys with x >= h are in nobody's window (the column bound uses h)
+            for (int qy = max(0, y - 2); qy < min(h, y + 3); ++qy)
+                for (int qx = max(0, x - 2); qx < min(w, x + 3); ++qx) {
+                    const long long qt = img0 + qy * w + qx;
+                    const size_t qo = (size_t)qt * 128 + head * 16;
+                    ld16(Q + qo, qi);
+                    ld16(dO + qo, di);
+                    const float* s3 = stats + ((size_t)qt * 8 + head) * 3;
+                    const float pij = expf(scale * dot16(qi, kj) - s3[0]) * s3[1];
+                    const float ds = pij * (dot16(di, vj) - s3[2]);
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) { dk[c] += ds * qi[c]; dv[c] += pij * di[c]; }
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dk[c] *= scale;
+        st16(dK + off, dk);
+        st16(dV + off, dv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Up-sampler tail (reference LFT.py:41-43,80): F = PixelShuffle(lrelu(U)) is never built; Aact = lrelu(U) stays
+// in token layout [N][64*s*s] (channel c*s*s + i*s + j <-> HR sub-pixel (i, j), LFT.py:41), and the mosaic-level
+// 3x3 conv 64 -> 1 reads it through the index map.  Mosaic HR pixel (Ym, Xm) <-> LR mosaic pixel (Ym/s, Xm/s) =
+// (a1*h + y, a2*w + x), sub-pixel (Ym % s, Xm % s).  Zero padding only at the mosaic border.
+// ------------------------------------------------------------------------------------------
+LFT_DEV long long up_token(int b, int Ym, int Xm, int A, int h, int w, int s, int& sub) {
+    const int ly = Ym / s, lx = Xm / s;
+    sub = (Ym - ly * s) * s + (Xm - lx * s);
+    const int a1 = ly / h, a2 = lx / w;
+    return (((long long)b * A * A + a1 * A + a2) * h + (ly - a1 * h)) * w + (lx - a2 * w);
+}
+// out[b][Ym][Xm] = skip[..] + sum_{c, tap} w3[c][tap] * F[c][Ym + dy][Xm + dx].  One thread per HR pixel.
+__global__ __launch_bounds__(256) void k_up_conv_fwd(const float* __restrict__ Aact, const float* __restrict__ w3,
+                                                     const float* __restrict__ skip, float* __restrict__ out,
+                                                     int B, int A, int h, int w, int s) {
+    __shared__ float wl[576];
+    for (int i = threadIdx.x; i < 576; i += 256) wl[i] = w3[i];
+    __syncthreads();
+    const int HH = A * h * s, WW = A * w * s, ss = s * s;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * HH * WW) return;
+    const int b = (int)(idx / ((long long)HH * WW));
+    const int rem = (int)(idx % ((long long)HH * WW)), Ym = rem / WW, Xm = rem % WW;
+    float acc = skip ? skip[idx] : 0.0f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = Ym + tap / 3 - 1, xx = Xm + tap % 3 - 1;
+        if (yy < 0 || yy >= HH || xx < 0 || xx >= WW) continue;
+        int sub;
+        const long long t = up_token(b, yy, xx, A, h, w, s, sub);
+        const float* row = Aact + t * 64 * ss + sub;
+        float a = 0.0f;
+        for (int c = 0; c < 64; ++c) a += wl[c * 9 + tap] * row[c * ss];
+        acc += a;
+    }
+    out[idx] = acc;
+}
+// Backward of the tail.  One wave per item = (token, sub-pixel); lane = channel c.
+//   dU[t][c*ss + sub] = lrelu'(Aact) * sum_tap w3[c][tap] * dout[Ym - dy][Xm - dx]
+//   dw3[c][tap]      += Aact[t][c*ss + sub] * dout[Ym - dy][Xm - dx]
+// Each wave walks a contiguous range of items and leaves its 64 x 9 partial sums in part[wave][576].
+__global__ __launch_bounds__(256) void k_up_conv_bwd(const float* __restrict__ Aact, const float* __restrict__ w3,
+                                                     const float* __restrict__ dout, float* __restrict__ dU,
+                                                     float* __restrict__ part, int B, int A, int h, int w, int s,
+                                                     long long items_per_wave) {
+    const int c = threadIdx.x & 63, ss = s * s;
+    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int HH = A * h * s, WW = A * w * s, V = A * A;
+    const long long nitems = (long long)B * V * h * w * ss;
+    float wr[9], dw[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { wr[t] = w3[c * 9 + t]; dw[t] = 0.0f; }
+    const long long i0 = wv * items_per_wave, i1 = min(i0 + items_per_wave, nitems);
+    for (long long it = i0; it < i1; ++it) {
+        const long long t = it / ss;
+        const int sub = (int)(it - t * ss);
+        const int x = (int)(t % w), y = (int)((t / w) % h), v = (int)((t / ((long long)w * h)) % V), b = (int)(t / ((long long)w * h * V));
+        const int Ym = ((v / A) * h + y) * s + sub / s, Xm = ((v % A) * w + x) * s + sub % s;
+        const float a = Aact[t * 64 * ss + c * ss + sub];
+        float g = 0.0f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = Ym - (tap / 3 - 1), xx = Xm - (tap % 3 - 1);      // the output pixel that read F here through `tap`
+            const bool ok = yy >= 0 && yy < HH && xx >= 0 && xx < WW;
+            const float d = ok ? dout[((long long)b * HH + yy) * WW + xx] : 0.0f;
+            g += wr[tap] * d;
+            dw[tap] += a * d;
+        }
+        dU[t * 64 * ss + c * ss + sub] = a > 0.0f ? g : 0.2f * g;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) part[wv * 576 + c * 9 + t] = dw[t];
+}
+
+// conv_init0 weight gradient (reference LFT.py:24): dW0[c][tap] = sum_t dX0[t][c] * lr[view pixel (y+dy, x+dx)].
+// One wave per token range, lane = channel.
+__global__ __launch_bounds__(256) void k_conv0_wgrad(const float* __restrict__ dX0, const float* __restrict__ lr,
+                                                     float* __restrict__ part, int B, int A, int h, int w, long long toks_per_wave) {
+    const int c = threadIdx.x & 63, V = A * A;
+    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long N = (long long)B * V * h * w;
+    float dw[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dw[t] = 0.0f;
+    const long long t0 = wv * toks_per_wave, t1 = min(t0 + toks_per_wave, N);
+    for (long long t = t0; t < t1; ++t) {
+        const int x = (int)(t % w), y = (int)((t / w) % h), v = (int)((t / ((long long)w * h)) % V), b = (int)(t / ((long long)w * h * V));
+        const float* img = lr + (size_t)b * (A * h) * (A * w) + (size_t)((v / A) * h) * (A * w) + (v % A) * w;
+        const float g = dX0[t * 64 + c];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            const float pv = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[yy * (A * w) + xx] : 0.0f;
+            dw[tap] += g * pv;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) part[wv * 576 + c * 9 + t] = dw[t];
+}
+
+// L1 loss (reference LFT.py:269-277) and its gradient: loss = mean |sr - hr|; dsr = sign(sr - hr) * gscale.
+__global__ __launch_bounds__(256) void k_l1_partial(const float* __restrict__ sr, const float* __restrict__ hr, float* __restrict__ dsr,
+                                                    float gscale, long long n, float* __restrict__ part) {
+    __shared__ float red[256];
+    float s = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = sr[i] - hr[i];
+        s += fabsf(d);
+        if (dsr) dsr[i] = d > 0.0f ? gscale : (d < 0.0f ? -gscale : 0.0f);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void k_l1_final(const float* __restrict__ part, int nb, float inv_n, float* __restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.0f;
+        for (int i = 0; i < nb; ++i) s += part[i];
+        *loss = s * inv_n;
+    }
+}
+
+// Adam (torch.optim.Adam defaults used by the reference, train.py:77-83: betas, eps, weight_decay 0), one flat
+// fp32 buffer of all parameters: p -= lr_t * m_hat / (sqrt(v_hat) + eps).  bc1 = 1 - b1^t, bc2 = 1 - b2^t.
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       long long n, float lr, float b1, float b2, float eps, float bc1, float bc2, float gscale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}

@@ -1,0 +1,356 @@
+// lft_train_host.cuh -- host orchestration of the fp32 training step (included inside lft_api.hip's anonymous
+// namespace): tape layout, forward with saved activations, backward into one flat gradient buffer.
+//
+// Counterpart of autograd over reference model/LFT.py:52-83 as driven by train.py:89-107.  Parameter indices follow
+// lft_amd/params.py:param_table (the reference's registration order); the flat gradient buffer holds the 78 gradients
+// back to back in that order, so a data-parallel job needs ONE all-reduce per step.
+#pragma once
+#include "lft_train.cuh"
+
+// ---- parameter indices ----
+constexpr int P_CONV0 = 0, P_CONV = 1, P_LAYER0 = 4, P_PER_LAYER = 18, P_UP0 = 76, P_UP3 = 77;
+enum { S_MLP = 0, S_N1W, S_N1B, S_INPROJ, S_OUT, S_N2W, S_N2B, S_FF1, S_FF2, S_LIN, A_N1W, A_N1B, A_INPROJ, A_OUT, A_N2W, A_N2B, A_FF1, A_FF2 };
+inline int pidx(int l, int which) { return P_LAYER0 + P_PER_LAYER * l + which; }
+
+struct ParamInfo { long long numel[LFT_NUM_PARAMS], off[LFT_NUM_PARAMS], total; };
+inline ParamInfo param_info(int s) {
+    ParamInfo pi;
+    int i = 0;
+    pi.numel[i++] = 576;
+    for (int k = 0; k < 3; ++k) pi.numel[i++] = 64 * 576;
+    for (int l = 0; l < kLayers; ++l) {
+        const long long sp[10] = {128 * 576, 128, 128, 384 * 128, 128 * 128, 128, 128, 256 * 128, 128 * 256, 64 * 128};
+        const long long an[8] = {64, 64, 192 * 64, 64 * 64, 64, 64, 128 * 64, 64 * 128};
+        for (long long v : sp) pi.numel[i++] = v;
+        for (long long v : an) pi.numel[i++] = v;
+    }
+    pi.numel[i++] = 64LL * s * s * 64;
+    pi.numel[i++] = 576;
+    long long o = 0;
+    for (int k = 0; k < LFT_NUM_PARAMS; ++k) { pi.off[k] = o; o += pi.numel[k]; }
+    pi.total = o;
+    return pi;
+}
+
+// ---- tape: everything the backward pass re-reads (floats, offsets in floats) ----
+struct AngTape { size_t n, qk, v, o, t1, m, hdn, y; };
+struct SpaTape { size_t petok, tok, n, q, k, v, o, t1, m, hdn, t2, y; };
+struct TrainLayout {
+    size_t pe_ang, pe_spa, x0, c1, c2, c3, feat;
+    AngTape ang[kLayers];
+    SpaTape spa[kLayers];
+    size_t body, act, skip;                      // act = lrelu(U) [N, 64 s^2]; skip = bicubic(lr)
+    // backward scratch
+    size_t g64[5], g128[5], g256, gu, stats, dpetok, part, pgb;
+    size_t part_floats, total;                   // total in floats
+};
+constexpr int kWgChunks = 128;                   // token chunks of a weight-gradient launch
+constexpr int kLnBlocks = 512;                   // workgroups (= partial rows) of a LayerNorm backward
+constexpr int kTailWaves = 2048;                 // waves of the up-sampler / conv0 weight-gradient kernels
+
+TrainLayout train_layout(const Dims& d) {
+    TrainLayout T;
+    size_t o = 0;
+    auto take = [&](size_t floats) { size_t r = o; o += (floats + 63) & ~(size_t)63; return r; };
+    const size_t n = (size_t)d.ntok, ss = (size_t)d.s * d.s;
+    T.pe_ang = take((size_t)d.V * 64); T.pe_spa = take((size_t)d.hw * 64);
+    T.x0 = take(n * 64); T.c1 = take(n * 64); T.c2 = take(n * 64); T.c3 = take(n * 64); T.feat = take(n * 64);
+    for (int l = 0; l < kLayers; ++l) {
+        AngTape& a = T.ang[l];
+        a.n = take(n * 64); a.qk = take(n * 128); a.v = take(n * 64); a.o = take(n * 64); a.t1 = take(n * 64);
+        a.m = take(n * 64); a.hdn = take(n * 128); a.y = take(n * 64);
+        SpaTape& sp = T.spa[l];
+        sp.petok = take((size_t)d.hw * 128);
+        sp.tok = take(n * 128); sp.n = take(n * 128); sp.q = take(n * 128); sp.k = take(n * 128); sp.v = take(n * 128);
+        sp.o = take(n * 128); sp.t1 = take(n * 128); sp.m = take(n * 128); sp.hdn = take(n * 256); sp.t2 = take(n * 128);
+        sp.y = take(n * 64);
+    }
+    T.body = take(n * 64); T.act = take(n * 64 * ss);
+    T.skip = take((size_t)d.B * d.A * d.h * d.s * d.A * d.w * d.s);
+    for (int i = 0; i < 5; ++i) T.g64[i] = take(n * 64);
+    for (int i = 0; i < 5; ++i) T.g128[i] = take(n * 128);
+    T.g256 = take(n * 256); T.gu = take(n * 64 * ss);
+    T.stats = take(n * 8 * 3); T.dpetok = take((size_t)d.hw * 128);
+    T.part_floats = std::max((size_t)kWgChunks * 128 * 576, (size_t)kTailWaves * 576);
+    T.part = take(T.part_floats);
+    T.pgb = take((size_t)kLnBlocks * 256);
+    T.total = o;
+    return T;
+}
+
+// ---- launch helpers ----
+struct TrainCtx {
+    const Dims& d;
+    float* tp;                 // tape base
+    const TrainLayout& T;
+    hipStream_t st;
+    float* F(size_t off) const { return tp + off; }
+};
+
+int run_lin(const TrainCtx& c, const float* X, int ldx, const float* W, int so, int si, int st_, int Ci, int Co, int taps, int flip,
+            int act, const float* R, int ldr, float* Y, int ldy, long long N, int h, int w) {
+    if (Ci % 16 || Co % 64) return fail(LFT_ERR_ARG, "run_lin: Ci %d / Co %d not supported", Ci, Co);
+    LinP p{X, ldx, W, so, si, st_, R, ldr, Y, ldy, Ci, Co, taps, flip, act, h, w, N};
+    const bool contig = si == 1 && taps == 1 && so % 4 == 0;
+    const unsigned gx = (unsigned)((N + 127) / 128);
+    if (Co % 128 == 0) {
+        const dim3 g(gx, (unsigned)(Co / 128));
+        if (contig) k_lin<4, true><<<g, 256, 0, c.st>>>(p); else k_lin<4, false><<<g, 256, 0, c.st>>>(p);
+    } else {
+        const dim3 g(gx, (unsigned)(Co / 64));
+        if (contig) k_lin<2, true><<<g, 256, 0, c.st>>>(p); else k_lin<2, false><<<g, 256, 0, c.st>>>(p);
+    }
+    LFT_LAUNCH_OK("k_lin");
+    return 0;
+}
+// plain Linear: Y = act(X W^T) (+R), W [Co][Ci] row-major
+int lin_fwd(const TrainCtx& c, const float* X, const float* W, int Ci, int Co, int act, const float* R, float* Y, long long N) {
+    return run_lin(c, X, Ci, W, Ci, 1, 0, Ci, Co, 1, 0, act, R, Co, Y, Co, N, c.d.h, c.d.w);
+}
+// its input gradient: dX = dY W (+R), i.e. a Linear with the transposed weight
+int lin_bwd(const TrainCtx& c, const float* dY, const float* W, int Ci, int Co, const float* R, float* dX, long long N) {
+    return run_lin(c, dY, Co, W, 1, Ci, 0, Co, Ci, 1, 0, 0, R, Ci, dX, Ci, N, c.d.h, c.d.w);
+}
+// per-view 3x3 conv, weight [Co][Ci][3][3] (the unfold-MLP weight [Co][Ci*9] has the same element order, LFT.py:167)
+int conv_fwd(const TrainCtx& c, const float* X, const float* W, int Ci, int Co, int act, const float* R, float* Y, long long N) {
+    return run_lin(c, X, Ci, W, Ci * 9, 9, 1, Ci, Co, 9, 0, act, R, Co, Y, Co, N, c.d.h, c.d.w);
+}
+int conv_bwd(const TrainCtx& c, const float* dY, const float* W, int Ci, int Co, const float* R, float* dX, long long N) {
+    return run_lin(c, dY, Co, W, 9, Ci * 9, 1, Co, Ci, 9, 1, 0, R, Ci, dX, Ci, N, c.d.h, c.d.w);
+}
+// weight gradient of either: dW (+)= dY^T X  (taps = 1 or 9)
+int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, int taps, float* dW, int accumulate, long long N) {
+    if (Co % 32 || Ci % 64) return fail(LFT_ERR_ARG, "wgrad: Co %d / Ci %d not supported", Co, Ci);
+    const long long wsize = (long long)Co * Ci * taps;
+    int nch = kWgChunks;
+    while (nch > 1 && (size_t)nch * wsize > c.T.part_floats) nch >>= 1;
+    long long len = (N + nch - 1) / nch;
+    len = (len + 15) & ~15LL;
+    WgP p{dY, Co, X, Ci, c.F(c.T.part), wsize, Ci * taps, taps, 1, Co, Ci, taps, c.d.h, c.d.w, N, len, 1};
+    if (Ci % 128 == 0) {
+        p.igroups = Ci / 128;
+        k_wgrad<4><<<dim3((unsigned)nch, (unsigned)(Co / 32 * p.igroups), (unsigned)taps), 64, 0, c.st>>>(p);
+    } else {
+        p.igroups = Ci / 64;
+        k_wgrad<2><<<dim3((unsigned)nch, (unsigned)(Co / 32 * p.igroups), (unsigned)taps), 64, 0, c.st>>>(p);
+    }
+    LFT_LAUNCH_OK("k_wgrad");
+    k_reduce<<<blocks_for(wsize, 256), 256, 0, c.st>>>(c.F(c.T.part), nch, wsize, wsize, dW, accumulate);
+    LFT_LAUNCH_OK("k_reduce");
+    return 0;
+}
+int ln_fwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, const float* g, const float* b, float* Y, long long N) {
+    if (C == 64) k_ln_fwd<64><<<blocks_for(N, 16), 256, 0, c.st>>>(X, pe, mode, g, b, Y, N, c.d.hw, c.d.V);
+    else k_ln_fwd<128><<<blocks_for(N, 16), 256, 0, c.st>>>(X, pe, mode, g, b, Y, N, c.d.hw, c.d.V);
+    LFT_LAUNCH_OK("k_ln_fwd");
+    return 0;
+}
+// out = (add ? add : 0) + dLN/du ; dgamma, dbeta written
+int ln_bwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, const float* g, const float* dY, const float* add,
+           float* out, float* dgamma, float* dbeta, long long N) {
+    const int nb = (int)std::min<long long>(kLnBlocks, (N + 15) / 16);
+    if (C == 64) k_ln_bwd<64><<<nb, 256, 0, c.st>>>(X, pe, mode, g, dY, add, out, c.F(c.T.pgb), N, c.d.hw, c.d.V);
+    else k_ln_bwd<128><<<nb, 256, 0, c.st>>>(X, pe, mode, g, dY, add, out, c.F(c.T.pgb), N, c.d.hw, c.d.V);
+    LFT_LAUNCH_OK("k_ln_bwd");
+    // pgb rows are [dgamma(C) | dbeta(C)]
+    k_reduce<<<blocks_for(C, 256), 256, 0, c.st>>>(c.F(c.T.pgb), nb, C, 2 * C, dgamma, 0);
+    LFT_LAUNCH_OK("k_reduce");
+    k_reduce<<<blocks_for(C, 256), 256, 0, c.st>>>(c.F(c.T.pgb) + C, nb, C, 2 * C, dbeta, 0);
+    LFT_LAUNCH_OK("k_reduce");
+    return 0;
+}
+int act_bwd(const TrainCtx& c, const float* g, const float* y, float* out, long long n, int mode) {
+    k_act_bwd<<<blocks_for(n / 4, 256), 256, 0, c.st>>>(g, y, out, n / 4, mode);
+    LFT_LAUNCH_OK("k_act_bwd");
+    return 0;
+}
+int add_to(const TrainCtx& c, float* a, const float* b, long long n) {
+    k_add<<<blocks_for(n / 4, 256), 256, 0, c.st>>>(a, b, n / 4);
+    LFT_LAUNCH_OK("k_add");
+    return 0;
+}
+template <bool BWD>
+int ang_attn(const TrainCtx& c, const float* QK, const float* Vv, float* O, const float* dO, float* dQK, float* dV) {
+    const int V = c.d.V, npix = c.d.B * c.d.hw;
+    int rc;
+    if (V <= 32) {
+        const size_t lds = BWD ? (size_t)(4 * 8 * 32 * 8 + 8 * 32 * 3) * 4 : (size_t)(2 * 8 * 32 * 8) * 4;
+        k_ang_attn<32, BWD><<<npix, 256, lds, c.st>>>(QK, Vv, O, dO, dQK, dV, V, c.d.hw);
+    } else {
+        const size_t lds = BWD ? (size_t)(4 * 8 * 128 * 8 + 8 * 128 * 3) * 4 : (size_t)(2 * 8 * 128 * 8) * 4;
+        if ((rc = allow_lds(k_ang_attn<128, BWD>, lds, "k_ang_attn"))) return rc;
+        k_ang_attn<128, BWD><<<npix, 1024, lds, c.st>>>(QK, Vv, O, dO, dQK, dV, V, c.d.hw);
+    }
+    LFT_LAUNCH_OK("k_ang_attn");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- forward with tape
+int train_forward(const float* const* P, const float* lr, float* out, float* tape, const Dims& d, hipStream_t st) {
+    const TrainLayout T = train_layout(d);
+    const TrainCtx c{d, tape, T, st};
+    const long long N = d.ntok;
+    const int nimg = d.B * d.V, ss = d.s * d.s;
+    int rc;
+#define TRY(x) do { if ((rc = (x))) return rc; } while (0)
+    k_pe_plain<<<blocks_for(std::max(d.V, d.hw) * 64, 256), 256, 0, st>>>(c.F(T.pe_ang), c.F(T.pe_spa), d.V, d.h, d.w);
+    LFT_LAUNCH_OK("k_pe_plain");
+    // conv_init0, conv_init + residual (LFT.py:65-66)
+    k_conv0<float><<<dim3((unsigned)((d.hw + 31) / 32), (unsigned)nimg), 256, 0, st>>>(lr, P[P_CONV0], c.F(T.x0), d.B, d.A, d.h, d.w);
+    LFT_LAUNCH_OK("k_conv0");
+    TRY(conv_fwd(c, c.F(T.x0), P[P_CONV + 0], 64, 64, 2, nullptr, c.F(T.c1), N));
+    TRY(conv_fwd(c, c.F(T.c1), P[P_CONV + 1], 64, 64, 2, nullptr, c.F(T.c2), N));
+    TRY(conv_fwd(c, c.F(T.c2), P[P_CONV + 2], 64, 64, 2, nullptr, c.F(T.c3), N));
+    LFT_HIP_OK(hipMemcpyAsync(c.F(T.feat), c.F(T.c3), (size_t)N * 64 * 4, hipMemcpyDeviceToDevice, st));
+    TRY(add_to(c, c.F(T.feat), c.F(T.x0), N * 64));
+    const float* x = c.F(T.feat);
+    for (int l = 0; l < kLayers; ++l) {
+        // ---- AngTrans (LFT.py:225-238) ----
+        const AngTape& a = T.ang[l];
+        const float* Win = P[pidx(l, A_INPROJ)];
+        TRY(ln_fwd(c, 64, x, c.F(T.pe_ang), 1, P[pidx(l, A_N1W)], P[pidx(l, A_N1B)], c.F(a.n), N));
+        TRY(lin_fwd(c, c.F(a.n), Win, 64, 128, 0, nullptr, c.F(a.qk), N));                 // Q | K from the normed tokens
+        TRY(lin_fwd(c, x, Win + 128 * 64, 64, 64, 0, nullptr, c.F(a.v), N));               // V from the raw tokens
+        TRY(ang_attn<false>(c, c.F(a.qk), c.F(a.v), c.F(a.o), nullptr, nullptr, nullptr));
+        TRY(lin_fwd(c, c.F(a.o), P[pidx(l, A_OUT)], 64, 64, 0, x, c.F(a.t1), N));
+        TRY(ln_fwd(c, 64, c.F(a.t1), nullptr, 0, P[pidx(l, A_N2W)], P[pidx(l, A_N2B)], c.F(a.m), N));
+        TRY(lin_fwd(c, c.F(a.m), P[pidx(l, A_FF1)], 64, 128, 1, nullptr, c.F(a.hdn), N));
+        TRY(lin_fwd(c, c.F(a.hdn), P[pidx(l, A_FF2)], 128, 64, 0, c.F(a.t1), c.F(a.y), N));
+        x = c.F(a.y);
+        // ---- SpaTrans (LFT.py:176-191) ----
+        const SpaTape& sp = T.spa[l];
+        const float* Wsp = P[pidx(l, S_INPROJ)];
+        TRY(conv_fwd(c, x, P[pidx(l, S_MLP)], 64, 128, 0, nullptr, c.F(sp.tok), N));
+        TRY(conv_fwd(c, c.F(T.pe_spa), P[pidx(l, S_MLP)], 64, 128, 0, nullptr, c.F(sp.petok), d.hw));   // LFT.py:180
+        TRY(ln_fwd(c, 128, c.F(sp.tok), c.F(sp.petok), 2, P[pidx(l, S_N1W)], P[pidx(l, S_N1B)], c.F(sp.n), N));
+        TRY(lin_fwd(c, c.F(sp.n), Wsp, 128, 128, 0, nullptr, c.F(sp.q), N));
+        TRY(lin_fwd(c, c.F(sp.n), Wsp + 128 * 128, 128, 128, 0, nullptr, c.F(sp.k), N));
+        TRY(lin_fwd(c, c.F(sp.tok), Wsp + 256 * 128, 128, 128, 0, nullptr, c.F(sp.v), N));
+        k_win_attn<0><<<blocks_for(N * 8, 256), 256, 0, st>>>(c.F(sp.q), c.F(sp.k), c.F(sp.v), c.F(sp.o), nullptr, nullptr, nullptr,
+                                                            nullptr, nullptr, N, d.h, d.w);
+        LFT_LAUNCH_OK("k_win_attn");
+        TRY(lin_fwd(c, c.F(sp.o), P[pidx(l, S_OUT)], 128, 128, 0, c.F(sp.tok), c.F(sp.t1), N));
+        TRY(ln_fwd(c, 128, c.F(sp.t1), nullptr, 0, P[pidx(l, S_N2W)], P[pidx(l, S_N2B)], c.F(sp.m), N));
+        TRY(lin_fwd(c, c.F(sp.m), P[pidx(l, S_FF1)], 128, 256, 1, nullptr, c.F(sp.hdn), N));
+        TRY(lin_fwd(c, c.F(sp.hdn), P[pidx(l, S_FF2)], 256, 128, 0, c.F(sp.t1), c.F(sp.t2), N));
+        const bool last = l == kLayers - 1;                                               // + global skip, LFT.py:76
+        TRY(lin_fwd(c, c.F(sp.t2), P[pidx(l, S_LIN)], 128, 64, 0, last ? c.F(T.feat) : nullptr, last ? c.F(T.body) : c.F(sp.y), N));
+        x = last ? c.F(T.body) : c.F(sp.y);
+    }
+    // ---- up-sampler + bicubic skip (LFT.py:79-81) ----
+    TRY(lin_fwd(c, c.F(T.body), P[P_UP0], 64, 64 * ss, 2, nullptr, c.F(T.act), N));
+    launch_assemble(lr, nullptr, c.F(T.skip), d.B, d.A, d.h, d.w, d.s, 0, st);
+    LFT_LAUNCH_OK("k_assemble");
+    const long long npx = (long long)d.B * d.A * d.h * d.s * d.A * d.w * d.s;
+    k_up_conv_fwd<<<blocks_for(npx, 256), 256, 0, st>>>(c.F(T.act), P[P_UP3], c.F(T.skip), out, d.B, d.A, d.h, d.w, d.s);
+    LFT_LAUNCH_OK("k_up_conv_fwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- backward
+int train_backward(const float* const* P, const float* lr, float* tape, const float* dout, float* G, const Dims& d, hipStream_t st) {
+    const TrainLayout T = train_layout(d);
+    const TrainCtx c{d, tape, T, st};
+    const ParamInfo pi = param_info(d.s);
+    const long long N = d.ntok;
+    const int ss = d.s * d.s, nimg = d.B * d.V;
+    int rc;
+    auto g = [&](int idx) { return G + pi.off[idx]; };
+    float *gskip = c.F(T.g64[0]), *ga = c.F(T.g64[1]), *gb = c.F(T.g64[2]), *t64a = c.F(T.g64[3]), *t64b = c.F(T.g64[4]);
+    float *h0 = c.F(T.g128[0]), *h1 = c.F(T.g128[1]), *h2 = c.F(T.g128[2]), *h3 = c.F(T.g128[3]), *h4 = c.F(T.g128[4]);
+    float* g256 = c.F(T.g256);
+    // ---- up-sampler tail ----
+    {
+        const long long nitems = N * ss, per = (nitems + kTailWaves - 1) / kTailWaves;
+        k_up_conv_bwd<<<kTailWaves / 4, 256, 0, st>>>(c.F(T.act), P[P_UP3], dout, c.F(T.gu), c.F(T.part), d.B, d.A, d.h, d.w, d.s, per);
+        LFT_LAUNCH_OK("k_up_conv_bwd");
+        k_reduce<<<blocks_for(576, 256), 256, 0, st>>>(c.F(T.part), kTailWaves, 576, 576, g(P_UP3), 0);
+        LFT_LAUNCH_OK("k_reduce");
+        TRY(wgrad(c, c.F(T.gu), 64 * ss, c.F(T.body), 64, 1, g(P_UP0), 0, N));
+        TRY(lin_bwd(c, c.F(T.gu), P[P_UP0], 64, 64 * ss, nullptr, gskip, N));          // d body = d y3 = d feat (global skip)
+    }
+    const float* dy = gskip;
+    for (int l = kLayers - 1; l >= 0; --l) {
+        // ================= SpaTrans backward: dy [N,64] -> dx in ga =================
+        {
+            const SpaTape& sp = T.spa[l];
+            const float* xin = c.F(T.ang[l].y);
+            const float* Wsp = P[pidx(l, S_INPROJ)];
+            float* gin = g(pidx(l, S_INPROJ));
+            TRY(wgrad(c, dy, 64, c.F(sp.t2), 128, 1, g(pidx(l, S_LIN)), 0, N));
+            TRY(lin_bwd(c, dy, P[pidx(l, S_LIN)], 128, 64, nullptr, h0, N));                         // d t2
+            TRY(wgrad(c, h0, 128, c.F(sp.hdn), 256, 1, g(pidx(l, S_FF2)), 0, N));
+            TRY(lin_bwd(c, h0, P[pidx(l, S_FF2)], 256, 128, nullptr, g256, N));                      // d hdn
+            TRY(act_bwd(c, g256, c.F(sp.hdn), g256, N * 256, 1));
+            TRY(wgrad(c, g256, 256, c.F(sp.m), 128, 1, g(pidx(l, S_FF1)), 0, N));
+            TRY(lin_bwd(c, g256, P[pidx(l, S_FF1)], 128, 256, nullptr, h1, N));                      // d m
+            TRY(ln_bwd(c, 128, c.F(sp.t1), nullptr, 0, P[pidx(l, S_N2W)], h1, h0, h0, g(pidx(l, S_N2W)), g(pidx(l, S_N2B)), N));   // h0 = d t1
+            TRY(wgrad(c, h0, 128, c.F(sp.o), 128, 1, g(pidx(l, S_OUT)), 0, N));
+            TRY(lin_bwd(c, h0, P[pidx(l, S_OUT)], 128, 128, nullptr, h1, N));                        // h1 = d O
+            k_win_attn<1><<<blocks_for(N * 8, 256), 256, 0, st>>>(c.F(sp.q), c.F(sp.k), c.F(sp.v), nullptr, h1, h2, nullptr, nullptr,
+                                                                c.F(T.stats), N, d.h, d.w);          // h2 = dQ
+            LFT_LAUNCH_OK("k_win_attn");
+            k_win_attn<2><<<blocks_for(N * 8, 256), 256, 0, st>>>(c.F(sp.q), c.F(sp.k), c.F(sp.v), nullptr, h1, nullptr, h3, h4,
+                                                                c.F(T.stats), N, d.h, d.w);          // h3 = dK, h4 = dV
+            LFT_LAUNCH_OK("k_win_attn");
+            TRY(wgrad(c, h4, 128, c.F(sp.tok), 128, 1, gin + 256 * 128, 0, N));
+            TRY(lin_bwd(c, h4, Wsp + 256 * 128, 128, 128, h0, h0, N));                               // d tok += dV Wv
+            TRY(wgrad(c, h2, 128, c.F(sp.n), 128, 1, gin, 0, N));
+            TRY(wgrad(c, h3, 128, c.F(sp.n), 128, 1, gin + 128 * 128, 0, N));
+            TRY(lin_bwd(c, h2, Wsp, 128, 128, nullptr, h1, N));
+            TRY(lin_bwd(c, h3, Wsp + 128 * 128, 128, 128, h1, h1, N));                               // h1 = d n
+            TRY(ln_bwd(c, 128, c.F(sp.tok), c.F(sp.petok), 2, P[pidx(l, S_N1W)], h1, nullptr, h2, g(pidx(l, S_N1W)), g(pidx(l, S_N1B)), N));  // h2 = d(tok+pe)
+            k_sum_images<<<blocks_for((long long)d.hw * 128, 256), 256, 0, st>>>(h2, nimg, (long long)d.hw * 128, c.F(T.dpetok));
+            LFT_LAUNCH_OK("k_sum_images");
+            TRY(add_to(c, h0, h2, N * 128));                                                         // h0 = d tok (total)
+            TRY(wgrad(c, h0, 128, xin, 64, 9, g(pidx(l, S_MLP)), 0, N));
+            {   // the position tokens are MLP(unfold(PE)) too (LFT.py:180): one more image of N = hw tokens
+                TRY(wgrad(c, c.F(T.dpetok), 128, c.F(T.pe_spa), 64, 9, g(pidx(l, S_MLP)), 1, d.hw));
+            }
+            TRY(conv_bwd(c, h0, P[pidx(l, S_MLP)], 64, 128, nullptr, ga, N));                        // ga = d x_in
+        }
+        // ================= AngTrans backward: ga -> gb =================
+        {
+            const AngTape& a = T.ang[l];
+            const float* xin = l == 0 ? c.F(T.feat) : c.F(T.spa[l - 1].y);
+            const float* Win = P[pidx(l, A_INPROJ)];
+            float* gin = g(pidx(l, A_INPROJ));
+            TRY(wgrad(c, ga, 64, c.F(a.hdn), 128, 1, g(pidx(l, A_FF2)), 0, N));
+            TRY(lin_bwd(c, ga, P[pidx(l, A_FF2)], 128, 64, nullptr, h0, N));                         // d hdn
+            TRY(act_bwd(c, h0, c.F(a.hdn), h0, N * 128, 1));
+            TRY(wgrad(c, h0, 128, c.F(a.m), 64, 1, g(pidx(l, A_FF1)), 0, N));
+            TRY(lin_bwd(c, h0, P[pidx(l, A_FF1)], 64, 128, nullptr, t64a, N));                       // d m
+            TRY(ln_bwd(c, 64, c.F(a.t1), nullptr, 0, P[pidx(l, A_N2W)], t64a, ga, gb, g(pidx(l, A_N2W)), g(pidx(l, A_N2B)), N));   // gb = d t1
+            TRY(wgrad(c, gb, 64, c.F(a.o), 64, 1, g(pidx(l, A_OUT)), 0, N));
+            TRY(lin_bwd(c, gb, P[pidx(l, A_OUT)], 64, 64, nullptr, t64a, N));                        // d o
+            TRY(ang_attn<true>(c, c.F(a.qk), c.F(a.v), nullptr, t64a, h0, t64b));                    // h0 = dQK, t64b = dV
+            TRY(wgrad(c, t64b, 64, xin, 64, 1, gin + 128 * 64, 0, N));
+            TRY(lin_bwd(c, t64b, Win + 128 * 64, 64, 64, gb, gb, N));                                // d x += dV Wv
+            TRY(wgrad(c, h0, 128, c.F(a.n), 64, 1, gin, 0, N));
+            TRY(lin_bwd(c, h0, Win, 64, 128, nullptr, t64a, N));                                     // d n
+            TRY(ln_bwd(c, 64, xin, c.F(T.pe_ang), 1, P[pidx(l, A_N1W)], t64a, gb, gb, g(pidx(l, A_N1W)), g(pidx(l, A_N1B)), N));
+        }
+        dy = gb;
+        // next iteration's SpaTrans writes ga, AngTrans writes gb while reading ga: dy = gb is only read by the SpaTrans part
+    }
+    // ---- initial feature extractor: d feat = gb + gskip ----
+    TRY(add_to(c, gb, gskip, N * 64));
+    TRY(act_bwd(c, gb, c.F(T.c3), ga, N * 64, 2));                                                   // d z3
+    TRY(wgrad(c, ga, 64, c.F(T.c2), 64, 9, g(P_CONV + 2), 0, N));
+    TRY(conv_bwd(c, ga, P[P_CONV + 2], 64, 64, nullptr, gskip, N));                                  // d c2
+    TRY(act_bwd(c, gskip, c.F(T.c2), gskip, N * 64, 2));
+    TRY(wgrad(c, gskip, 64, c.F(T.c1), 64, 9, g(P_CONV + 1), 0, N));
+    TRY(conv_bwd(c, gskip, P[P_CONV + 1], 64, 64, nullptr, ga, N));                                  // d c1
+    TRY(act_bwd(c, ga, c.F(T.c1), ga, N * 64, 2));
+    TRY(wgrad(c, ga, 64, c.F(T.x0), 64, 9, g(P_CONV + 0), 0, N));
+    TRY(conv_bwd(c, ga, P[P_CONV + 0], 64, 64, gb, gb, N));                                          // d x0 = d feat + conv path
+    {
+        const long long per = (N + kTailWaves - 1) / kTailWaves;
+        k_conv0_wgrad<<<kTailWaves / 4, 256, 0, st>>>(gb, lr, c.F(T.part), d.B, d.A, d.h, d.w, per);
+        LFT_LAUNCH_OK("k_conv0_wgrad");
+        k_reduce<<<blocks_for(576, 256), 256, 0, st>>>(c.F(T.part), kTailWaves, 576, 576, g(P_CONV0), 0);
+        LFT_LAUNCH_OK("k_reduce");
+    }
+#undef TRY
+    return 0;
+}

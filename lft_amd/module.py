@@ -112,13 +112,15 @@ class get_model(nn.Module):
             raise ValueError(f"expected [B,1,A*h,A*w], got {tuple(lr.shape)}")
         if not lr.is_cuda:
             raise _lib.LftError("lft_amd runs on a HIP device only (no CPU fallback); move the input and the model to 'cuda'")
-        if torch.is_grad_enabled() and (lr.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise _lib.LftError("backward is not implemented in this build: call under torch.no_grad() "
-                                "(training path is listed as 'next' in DESIGN.md)")
         A, s = self.angRes, self.factor
         B, _, H, W = lr.shape
         if H % A or W % A:
             raise ValueError(f"mosaic {H}x{W} is not divisible by angRes {A}")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training (reference train.py:89-107): the fp32 forward-with-tape / backward kernels, whatever self.precision
+            # says; gradients reach the 78 parameters, none flows to the input (the reference's data has none either)
+            from .train import LFTFunction
+            return LFTFunction.apply(lr.contiguous().float(), A, s, *self._params_in_order())
         h, w = H // A, W // A
         x = lr.contiguous().float()
         prec = _PREC[self.precision]

@@ -1,0 +1,179 @@
+"""Training side of the plugin surface: what the reference gets from PyTorch autograd when ``train.py:89-107`` runs
+``net(data) -> criterion -> loss.backward() -> optimizer.step()`` -- here the forward-with-tape and the backward of
+the whole network are liblft_hip.so calls (fp32 kernels, lft_amd/csrc/lft_train*.cuh).
+
+Two ways in:
+  * ``get_model.forward`` under autograd returns a tensor whose ``grad_fn`` is :class:`LFTFunction`; ``loss.backward()``
+    fills ``p.grad`` of the 78 parameters, so the reference's ``torch.optim.Adam`` loop works unchanged.
+  * :class:`TrainStep` is the MI355X-first loop: parameters, gradients and Adam moments live in three flat fp32
+    buffers (the module's parameters become views), the loss gradient, backward, ONE all-reduce over RCCL and the
+    fused Adam update are five enqueues per step.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from .params import param_table
+
+
+def tape_bytes(B, A, h, w, s) -> int:
+    n = ctypes.c_size_t(0)
+    _lib.check(_lib.lib().lft_train_tape_bytes(B, A, h, w, s, ctypes.byref(n)), "lft_train_tape_bytes")
+    return n.value
+
+
+def grad_floats(s) -> int:
+    n = ctypes.c_size_t(0)
+    _lib.check(_lib.lib().lft_train_grad_floats(s, ctypes.byref(n)), "lft_train_grad_floats")
+    return n.value
+
+
+def tape_view(tape: torch.Tensor, name: str, B, A, h, w, s, shape) -> torch.Tensor:
+    """A saved activation of the last lft_train_forward as a tensor view (tests / debugging)."""
+    off = ctypes.c_size_t(0)
+    _lib.check(_lib.lib().lft_train_tape_offset(name.encode(), B, A, h, w, s, ctypes.byref(off)), "lft_train_tape_offset")
+    n = 1
+    for d in shape:
+        n *= d
+    return tape.view(torch.float32)[off.value:off.value + n].view(*shape)
+
+
+def _check_params(ps: List[torch.Tensor], dev) -> None:
+    if len(ps) != _lib.NUM_PARAMS:
+        raise _lib.LftError(f"expected {_lib.NUM_PARAMS} parameters, got {len(ps)}")
+    for p in ps:
+        if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
+            raise _lib.LftError(f"all parameters must be contiguous float32 tensors on {dev}; call net.to(device) first")
+
+
+def _ptr_array(ps):
+    return (ctypes.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
+
+
+def train_forward(ps, lr, A, s, tape=None):
+    """lft_train_forward: returns (out, tape)."""
+    B, _, H, W = lr.shape
+    h, w = H // A, W // A
+    dev = lr.device
+    _check_params(ps, dev)
+    if tape is None:
+        tape = torch.empty(tape_bytes(B, A, h, w, s), dtype=torch.uint8, device=dev)
+    out = torch.empty((B, 1, H * s, W * s), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(_lib.lib().lft_train_forward(_ptr_array(ps), len(ps), lr.data_ptr(), out.data_ptr(), tape.data_ptr(),
+                                            B, A, h, w, s, stream), "lft_train_forward")
+    return out, tape
+
+
+def train_backward(ps, lr, tape, dout, A, s, grads=None):
+    """lft_train_backward: returns the flat gradient buffer (78 gradients back to back, state_dict order)."""
+    B, _, H, W = lr.shape
+    h, w = H // A, W // A
+    dev = lr.device
+    if grads is None:
+        grads = torch.empty(grad_floats(s), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(_lib.lib().lft_train_backward(_ptr_array(ps), len(ps), lr.data_ptr(), tape.data_ptr(), dout.data_ptr(), grads.data_ptr(),
+                                             B, A, h, w, s, stream), "lft_train_backward")
+    return grads
+
+
+class LFTFunction(torch.autograd.Function):
+    """autograd node of the whole network: forward saves the tape, backward returns the 78 parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, lr, A, s, *params):
+        ps = [p.detach() for p in params]
+        with torch.cuda.device(lr.device):
+            out, tape = train_forward(ps, lr, A, s)
+        ctx.A, ctx.s, ctx.tape, ctx.lr = A, s, tape, lr
+        ctx.save_for_backward(*params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ps = [p.detach() for p in ctx.saved_tensors]
+        with torch.cuda.device(dout.device):
+            flat = train_backward(ps, ctx.lr, ctx.tape, dout.contiguous().float(), ctx.A, ctx.s)
+        ctx.tape = None
+        grads, off = [], 0
+        for p in ps:
+            grads.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        return (None, None, None, *grads)
+
+
+class TrainStep:
+    """One data-parallel training step of the reference's loop (train.py:89-107) with flat buffers.
+
+    net: lft_amd.module.get_model on a HIP device.  After construction the module's parameters are views into
+    ``self.flat_params`` (state_dict / checkpoints keep working).  ``step(lr, hr)`` returns the loss tensor (device
+    scalar, local shard).  With torch.distributed initialised, gradients are summed with ONE all-reduce of the flat
+    buffer and averaged inside the Adam kernel (L1Loss is a mean over the local shard, shards are equal: SURVEY 8e).
+    """
+
+    def __init__(self, net, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, process_group=None):
+        self.net, self.lr, self.betas, self.eps = net, float(lr), betas, float(eps)
+        self.group = process_group
+        ps = net._params_in_order()
+        dev = ps[0].device
+        _check_params(ps, dev)
+        self.s, self.A = net.factor, net.angRes
+        n = grad_floats(self.s)
+        assert n == sum(p.numel() for p in ps)
+        self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in ps:
+                k = p.numel()
+                self.flat_params[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat_params[off:off + k].view(p.shape)
+                p.grad = self.flat_grads[off:off + k].view(p.shape)
+                off += k
+        self.params = ps
+        self.t = 0
+        self._tape = None
+        self._scratch = torch.empty(1024 + 1, dtype=torch.float32, device=dev)
+
+    def world(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def step(self, lr_in: torch.Tensor, hr: torch.Tensor) -> torch.Tensor:
+        import torch.distributed as dist
+        dev = lr_in.device
+        B, _, H, W = lr_in.shape
+        h, w = H // self.A, W // self.A
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            nb = tape_bytes(B, self.A, h, w, self.s)
+            if self._tape is None or self._tape.numel() != nb:
+                self._tape = torch.empty(nb, dtype=torch.uint8, device=dev)
+            out, _ = train_forward(self.params, lr_in, self.A, self.s, tape=self._tape)
+            dout = torch.empty_like(out)
+            n = out.numel()
+            loss = self._scratch[1024:1025]
+            _lib.check(L.lft_l1_loss(out.data_ptr(), hr.data_ptr(), n, dout.data_ptr(), 1.0 / n, loss.data_ptr(),
+                                     self._scratch.data_ptr(), stream), "lft_l1_loss")
+            train_backward(self.params, lr_in, self._tape, dout, self.A, self.s, grads=self.flat_grads)
+            world = self.world()
+            if world > 1:
+                dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+            self.t += 1
+            _lib.check(L.lft_adam_step(self.flat_params.data_ptr(), self.flat_grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                       self.flat_params.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.t,
+                                       1.0 / world, stream), "lft_adam_step")
+        self.net._packed = None            # the inference path must re-pack the new weights
+        return loss.clone()
+
+
+def names(channels: int = 64, scale: int = 2):
+    return [n for n, _, _ in param_table(channels, scale)]

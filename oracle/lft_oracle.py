@@ -117,10 +117,25 @@ def mha(q_in: torch.Tensor, v_in: torch.Tensor, w_in: torch.Tensor, w_out: torch
     return o @ w_out.t()
 
 
-def ffn(t: torch.Tensor, ln_w, ln_b, w1, w2) -> torch.Tensor:
+# Branch override for gradient parity tests.  The network is piecewise linear at every ReLU / LeakyReLU: where a
+# pre-activation is within fp32 rounding of 0, two correct fp32 implementations take different branches and their
+# gradients differ at the 1e-3 level (worse at small token counts).  With `branch_masks` set to {tag: bool tensor in the
+# layout of the pre-activation}, the activation uses the GIVEN branch (True = positive side) instead of sign(z), so a
+# backward pass can be checked exactly against an implementation whose forward made the decisions.
+branch_masks: Optional[dict] = None
+
+
+def _act(z: torch.Tensor, tag: str, slope: float) -> torch.Tensor:
+    if branch_masks is not None and tag in branch_masks:
+        m = branch_masks[tag].to(z.dtype)
+        return z * (m + (1.0 - m) * slope)
+    return F.relu(z) if slope == 0.0 else F.leaky_relu(z, slope)
+
+
+def ffn(t: torch.Tensor, ln_w, ln_b, w1, w2, tag: str = "") -> torch.Tensor:
     """LayerNorm -> Linear -> ReLU -> Linear, no biases, dropout 0 (reference LFT.py:135-142, 207-214)."""
     n = F.layer_norm(t, (t.shape[-1],), ln_w, ln_b, 1e-5)
-    return F.relu(n @ w1.t()) @ w2.t()
+    return _act(n @ w1.t(), tag, 0.0) @ w2.t()
 
 
 # --------------------------------------------------------------------------------------------
@@ -136,7 +151,7 @@ def init_features(sd: Dict[str, torch.Tensor], lr_views: torch.Tensor) -> torch.
     f0 = conv_views(lr_views, sd["conv_init0.0.weight"])
     f = f0
     for i in (0, 2, 4):
-        f = F.leaky_relu(conv_views(f, sd[f"conv_init.{i}.weight"]), 0.2)
+        f = _act(conv_views(f, sd[f"conv_init.{i}.weight"]), f"conv{i}", 0.2)
     return f + f0
 
 
@@ -145,11 +160,11 @@ def ang_block(sd, l: int, x: torch.Tensor) -> torch.Tensor:
     p = f"altblock.{l}.ang_trans."
     B, C, V, h, w = x.shape
     t = x.permute(2, 0, 3, 4, 1).reshape(V, B * h * w, C)
-    pe = angular_pe(V, C).view(V, 1, C)
+    pe = angular_pe(V, C).view(V, 1, C).to(x.dtype)
     n = F.layer_norm(t + pe, (C,), sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5)
     t = mha(n, t, sd[p + "attention.in_proj_weight"], sd[p + "attention.out_proj.weight"], None) + t
     t = ffn(t, sd[p + "feed_forward.0.weight"], sd[p + "feed_forward.0.bias"],
-            sd[p + "feed_forward.1.weight"], sd[p + "feed_forward.4.weight"]) + t
+            sd[p + "feed_forward.1.weight"], sd[p + "feed_forward.4.weight"], f"ang{l}") + t
     return t.reshape(V, B, h, w, C).permute(1, 4, 0, 2, 3)
 
 
@@ -169,11 +184,11 @@ def spa_block(sd, l: int, x: torch.Tensor, mask: Optional[torch.Tensor] = None) 
     if mask is None:
         mask = window_mask(h, w)
     t = spa_tokens(x, sd[p + "MLP.weight"])
-    pe = spa_tokens(spatial_pe(h, w, C).view(1, C, 1, h, w), sd[p + "MLP.weight"])
+    pe = spa_tokens(spatial_pe(h, w, C).view(1, C, 1, h, w).to(x.dtype), sd[p + "MLP.weight"])
     n = F.layer_norm(t + pe, (2 * C,), sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5)
-    t = mha(n, t, sd[p + "attention.in_proj_weight"], sd[p + "attention.out_proj.weight"], mask) + t
+    t = mha(n, t, sd[p + "attention.in_proj_weight"], sd[p + "attention.out_proj.weight"], mask.to(x.dtype)) + t
     t = ffn(t, sd[p + "feed_forward.0.weight"], sd[p + "feed_forward.0.bias"],
-            sd[p + "feed_forward.1.weight"], sd[p + "feed_forward.4.weight"]) + t
+            sd[p + "feed_forward.1.weight"], sd[p + "feed_forward.4.weight"], f"spa{l}") + t
     t = t.reshape(h, w, B, V, 2 * C).permute(2, 4, 3, 0, 1)               # [B,2C,V,h,w]
     return F.conv3d(t, sd[p + "linear.0.weight"])
 
@@ -182,15 +197,22 @@ def upsample(sd, x_mosaic: torch.Tensor, s: int) -> torch.Tensor:
     """1x1 conv -> PixelShuffle(s) -> LeakyReLU 0.2 -> 3x3 conv over the whole mosaic
     (reference LFT.py:39-44, 80)."""
     u = F.conv2d(x_mosaic, sd["upsampling.0.weight"])
-    u = F.leaky_relu(F.pixel_shuffle(u, s), 0.2)
+    u = F.pixel_shuffle(_act(u, "up", 0.2), s)                            # elementwise, so it commutes with the shuffle
     return F.conv2d(u, sd["upsampling.3.weight"], padding=1)
 
 
-@torch.no_grad()
 def forward(sd: Dict[str, torch.Tensor], lr: torch.Tensor, A: int, s: int,
             taps: Optional[dict] = None) -> torch.Tensor:
     """get_model.forward (reference LFT.py:52-83).  lr [B,1,A*h,A*w] float32 -> [B,1,A*h*s,A*w*s].
-    ``taps`` (optional dict) receives intermediate activations in [B,C,V,h,w] layout."""
+    ``taps`` (optional dict) receives intermediate activations in [B,C,V,h,w] layout.
+    Runs without autograd unless a weight requires grad (loss_and_grads below)."""
+    if not any(v.requires_grad for v in sd.values()):
+        with torch.no_grad():
+            return _forward(sd, lr, A, s, taps)
+    return _forward(sd, lr, A, s, taps)
+
+
+def _forward(sd, lr, A, s, taps):
     skip = bicubic_skip(lr, A, s)
     x = init_features(sd, mosaic_to_views(lr, A))
     h, w = x.shape[-2:]
@@ -280,3 +302,50 @@ def views_to_scene_mosaic(x: torch.Tensor) -> torch.Tensor:
     """[A, A, H, W] -> [A*H, A*W] (reference test.py:100-101)."""
     A, _, H, W = x.shape
     return x.permute(0, 2, 1, 3).reshape(A * H, A * W)
+
+
+# ------------------------------------------------------------------------------------------------
+# Training step (reference train.py:74-107): autograd over the restatement above, and torch.optim.Adam's update rule
+# (betas (0.9, 0.999), eps 1e-8, weight_decay 0, train.py:77-83) written out.  Pinned by tests/golden/train_*.npz,
+# which were produced by the real reference network + torch.optim.Adam (tools/gen_golden.py:train_case).
+# ------------------------------------------------------------------------------------------------
+def loss_and_grads(sd: Dict[str, torch.Tensor], lr: torch.Tensor, hr: torch.Tensor, A: int, s: int):
+    """(loss, out, {name: d loss / d param}) with loss = L1Loss(forward(lr), hr)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    out = forward(leaves, lr, A, s)
+    loss = l1_loss(out, hr)
+    grads = torch.autograd.grad(loss, list(leaves.values()))
+    return loss.detach(), out.detach(), {k: g for k, g in zip(leaves.keys(), grads)}
+
+
+def param_grads(sd: Dict[str, torch.Tensor], lr: torch.Tensor, A: int, s: int, dout: torch.Tensor):
+    """{name: d<out, dout>/d param}: the vector-Jacobian product of the whole network for a given output gradient."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    out = forward(leaves, lr, A, s)
+    grads = torch.autograd.grad(out, list(leaves.values()), grad_outputs=dout)
+    return {k: g for k, g in zip(leaves.keys(), grads)}
+
+
+def adam_update(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, t: int, lr: float = 2e-4,
+                b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8):
+    """One torch.optim.Adam step (t counts from 1); returns (p, m, v)."""
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    denom = v.sqrt() / math.sqrt(1 - b2 ** t) + eps
+    return p - (lr / (1 - b1 ** t)) * m / denom, m, v
+
+
+def train_steps(sd: Dict[str, torch.Tensor], lr: torch.Tensor, hr: torch.Tensor, A: int, s: int, steps: int, rate: float = 2e-4):
+    """`steps` Adam steps on one batch; returns (losses, first-step grads, final state)."""
+    cur = {k: v.clone() for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
+    losses, first = [], None
+    for t in range(1, steps + 1):
+        loss, _, grads = loss_and_grads(cur, lr, hr, A, s)
+        losses.append(float(loss))
+        if first is None:
+            first = grads
+        for k in cur:
+            cur[k], m[k], v2[k] = adam_update(cur[k], grads[k], m[k], v2[k], t, rate)
+    return losses, first, cur

@@ -1,0 +1,195 @@
+"""GPU parity of the training step (reference train.py:89-107 through PyTorch autograd): the fp32 forward-with-tape and
+backward kernels, called through the C ABI, against (a) autograd over the CPU oracle on the same seeded inputs and
+(b) fixtures produced by the REAL reference network + torch.optim.Adam (tests/golden/train_*.npz).
+
+Tolerance (BASELINE.json north_star: 1e-3 relative fp32): every saved activation and every one of the 78 gradients
+within 1e-3 * max|ref| of that tensor (observed ~1e-6 / ~1e-5)."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from lft_amd import _lib, train as T
+from lft_amd.params import deterministic_state, param_table, synthetic_lr
+from oracle import lft_oracle as O
+from oracle.fixtures import sub_indices
+
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+CASES = [(3, 2, 2, 6, 6), (2, 4, 1, 8, 5), (5, 2, 1, 8, 8), (2, 2, 1, 5, 9),      # h < w: empty windows pass no gradient
+         (9, 2, 1, 4, 4), (3, 2, 1, 7, 5), (5, 2, 1, 16, 16)]                    # 81 views; ragged 32-token tiles (315 tokens); 6400 tokens
+# The network is piecewise linear (ReLU, LeakyReLU, |.|): when a pre-activation lies within fp32 rounding of 0, two
+# correct fp32 implementations take different branches and -- at small token counts, where one token is 1/300 of the
+# batch -- whole gradient tensors move by ~1e-3 (torch-fp32 against torch-fp64 shows the same).  tools/
+# train_grad_report.py diagnoses it: with input seed 0, case A3 7x5 has |z| = 1.6e-7 at unit 115 of token 210 in
+# spa_trans 1's FFN and exactly that row of feed_forward.1.weight deviates, then everything upstream of it.
+# So gradients are checked two ways:
+#   * exactly: the oracle's autograd is told to take the branches OUR forward took (O.branch_masks, from our tape) and
+#     to start from OUR d loss / d out -- every case, every gradient, tolerance 1e-3 (observed ~1e-5);
+#   * end to end against the untouched oracle / the reference fixtures, on inputs that do not sit on a kink
+#     (case A9 uses another fixed input seed for that, cases A3 7x5 and A5 16x16 skip it; everything is deterministic).
+INPUT_SEED = {(9, 2, 1, 4, 4): 3}
+ON_A_KINK = {(3, 2, 1, 7, 5), (5, 2, 1, 16, 16)}
+
+
+def make_inputs(A, s, B, h, w):
+    sd_np = deterministic_state(64, s, seed=1, flavor="stress")
+    lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=INPUT_SEED.get((A, s, B, h, w), 0)))
+    rng = np.random.Generator(np.random.PCG64([2, B, A, h, w, s]))
+    hr = torch.from_numpy(rng.random((B, 1, A * h * s, A * w * s), dtype=np.float32))
+    return sd_np, lr, hr
+
+
+@pytest.fixture(scope="module", params=CASES, ids=lambda c: "A%d_s%d_B%d_%dx%d" % c)
+def case(request):
+    A, s, B, h, w = request.param
+    sd_np, lr, hr = make_inputs(A, s, B, h, w)
+    sd = O.state_from_numpy(sd_np)
+    taps = {}
+    out_ref = O.forward(sd, lr, A, s, taps)
+    loss_ref, _, grads_ref = O.loss_and_grads(sd, lr, hr, A, s)
+    names = [n for n, _, _ in param_table(64, s)]
+    ps = [torch.from_numpy(sd_np[n]).to(G.DEV).contiguous() for n in names]
+    lr_d, hr_d = lr.to(G.DEV), hr.to(G.DEV)
+    out, tape = T.train_forward(ps, lr_d, A, s)
+    n = out.numel()
+    dout = torch.empty_like(out)
+    scratch = torch.empty(1025, device=G.DEV)
+    _lib.check(_lib.lib().lft_l1_loss(out.data_ptr(), hr_d.data_ptr(), n, dout.data_ptr(), 1.0 / n, scratch[1024:].data_ptr(),
+                                      scratch.data_ptr(), G.stream()), "lft_l1_loss")
+    flat = T.train_backward(ps, lr_d, tape, dout, A, s)
+    torch.cuda.synchronize()
+    return dict(sd=sd, A=A, s=s, B=B, h=h, w=w, names=names, ps=ps, lr=lr_d, hr=hr_d, out=out, tape=tape, flat=flat, loss=float(scratch[1024]),
+                taps=taps, out_ref=out_ref, loss_ref=float(loss_ref), grads_ref=grads_ref, dout=dout)
+
+
+def test_forward_tape_matches_oracle(case):
+    A, s, B, h, w = case["A"], case["s"], case["B"], case["h"], case["w"]
+    V = A * A
+    for name, key in [("feat", "feat")] + [(f"ang{l}.y", f"ang{l}") for l in range(4)] + [(f"spa{l}.y", f"spa{l}") for l in range(3)] + [("body", "body")]:
+        got = T.tape_view(case["tape"], name, B, A, h, w, s, (B, V, h, w, 64)).cpu().permute(0, 4, 1, 2, 3)
+        ref = case["taps"][key]
+        assert not torch.isnan(got).any(), name
+        assert G.rel_max(got, ref) <= TOL, f"{name}: " + G.err_report(got.contiguous(), ref)
+    got, ref = case["out"].cpu(), case["out_ref"]
+    print("train forward: " + G.err_report(got, ref))
+    assert G.rel_max(got, ref) <= TOL
+    assert abs(case["loss"] - case["loss_ref"]) <= 1e-5 * max(1.0, abs(case["loss_ref"]))
+
+
+def our_branches(case):
+    """ReLU / LeakyReLU decisions of OUR forward, from the tape, in the layouts of the oracle's pre-activations."""
+    A, s, B, h, w = case["A"], case["s"], case["B"], case["h"], case["w"]
+    V, ss = A * A, s * s
+    tv = lambda name, C: T.tape_view(case["tape"], name, B, A, h, w, s, (B, V, h, w, C)).cpu() > 0   # noqa: E731
+    m = {}
+    for i, name in zip((0, 2, 4), ("c1", "c2", "c3")):
+        m[f"conv{i}"] = tv(name, 64).permute(0, 4, 1, 2, 3)                                        # [B,64,V,h,w]
+    for l in range(4):
+        m[f"ang{l}"] = tv(f"ang{l}.hdn", 128).permute(1, 0, 2, 3, 4).reshape(V, B * h * w, 128)     # 'a (b h w) c'
+        m[f"spa{l}"] = tv(f"spa{l}.hdn", 256).permute(2, 3, 0, 1, 4).reshape(h * w, B * V, 256)     # '(h w) (b a) c'
+    m["up"] = O.views_to_mosaic(tv("act", 64 * ss).permute(0, 4, 1, 2, 3), A)                       # [B,64ss,A*h,A*w]
+    return m
+
+
+def compare_all(case, grads_ref, what):
+    off, worst = 0, (0.0, "")
+    for name, p in zip(case["names"], case["ps"]):
+        k = p.numel()
+        got = case["flat"][off:off + k].cpu().view(p.shape)
+        ref = grads_ref[name]
+        off += k
+        assert not torch.isnan(got).any(), name
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        rel = err / max(scale, 1e-12)
+        if rel > worst[0]:
+            worst = (rel, name)
+        assert err <= TOL * scale + 1e-10, f"{name}: " + G.err_report(got, ref)
+    assert off == case["flat"].numel()
+    print(f"{what}: worst gradient rel err {worst[0]:.2e} ({worst[1]})")
+
+
+def test_all_78_gradients_exact_given_our_branches(case):
+    O.branch_masks = our_branches(case)
+    try:
+        ref = O.param_grads(case["sd"], case["lr"].cpu(), case["A"], case["s"], case["dout"].cpu())
+    finally:
+        O.branch_masks = None
+    compare_all(case, ref, "backward given our branches")
+
+
+def test_all_78_gradients_match_oracle_autograd(case):
+    if (case["A"], case["s"], case["B"], case["h"], case["w"]) in ON_A_KINK:
+        pytest.skip("input sits on a ReLU kink (see the note at the top); covered exactly by the branch-given test")
+    compare_all(case, case["grads_ref"], "end to end vs oracle autograd")
+
+
+def test_backward_is_deterministic(case):
+    again = T.train_backward(case["ps"], case["lr"], case["tape"], case["dout"], case["A"], case["s"])
+    torch.cuda.synchronize()
+    assert torch.equal(again, case["flat"])
+
+
+@pytest.mark.parametrize("name", ["train_a3_s2_b2_6x6", "train_a2_s4_b1_8x5"])
+def test_train_step_matches_reference_fixture(name, golden_dir):
+    """TrainStep (flat buffers, C-ABI loss / backward / Adam) against the reference network + torch.optim.Adam."""
+    from model import LFT
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    A, s, B, h, w, wseed, iseed, tseed, steps = [int(v) for v in g["meta"]]
+    net = LFT.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=s))
+    sd = deterministic_state(64, s, seed=wseed, flavor=str(g["flavor"]))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to(G.DEV).train()
+    lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=iseed)).to(G.DEV)
+    hr = torch.from_numpy(g["hr"]).to(G.DEV)
+    ts = T.TrainStep(net, lr=2e-4)
+    losses = []
+    for step in range(steps):
+        losses.append(float(ts.step(lr, hr)))
+        if step == 0:
+            for k, p in net.named_parameters():
+                got = p.grad.detach().cpu().numpy().ravel()
+                ref = g[f"grad_{k}_sub"]
+                scale = max(float(np.abs(ref).max()), 1e-12)
+                assert np.abs(got[sub_indices(got.size)] - ref).max() <= TOL * scale + 1e-10, k
+    assert np.allclose(losses, g["losses"], rtol=0, atol=1e-5), (losses, g["losses"])
+    for k, p in net.state_dict().items():
+        got = p.cpu().numpy().ravel()
+        ref = g[f"post_{k}_sub"]
+        assert np.abs(got[sub_indices(got.size)] - ref).max() <= 1.05 * steps * 2e-4, k
+        assert np.mean(np.abs(got[sub_indices(got.size)] - ref)) <= 2e-5, k
+    # the inference path sees the updated weights
+    with torch.no_grad():
+        y = net.eval()(lr)
+    assert float((y - hr).abs().mean()) < losses[0]
+
+
+def test_autograd_surface_like_reference_train_py():
+    """net(data) -> criterion -> loss.backward() -> torch.optim.Adam, exactly the calls of train.py:89-107."""
+    from model import LFT
+    A, s, B, h, w = 3, 2, 2, 6, 6
+    sd_np, lr, hr = make_inputs(A, s, B, h, w)
+    net = LFT.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=s))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    net = net.to(G.DEV)
+    net.apply(LFT.weights_init)
+    crit = LFT.get_loss(None).to(G.DEV)
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=2e-4, betas=(0.9, 0.999), eps=1e-08, weight_decay=0)
+    opt.zero_grad()
+    out = net(lr.to(G.DEV))
+    assert out.requires_grad
+    loss = crit(out, hr.to(G.DEV))
+    loss.backward()
+    _, _, grads_ref = O.loss_and_grads(O.state_from_numpy(sd_np), lr, hr, A, s)
+    for k, p in net.named_parameters():
+        ref = grads_ref[k]
+        assert float((p.grad.cpu() - ref).abs().max()) <= TOL * float(ref.abs().max()) + 1e-10, k
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    opt.step()
+    assert all(not torch.equal(before[k], p) for k, p in net.named_parameters())

@@ -132,10 +132,52 @@ def tiling(ns):
     print(f"tiling -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def train_case(ref, name, A, s, B, h, w, wseed=1, iseed=0, tseed=2, flavor="stress", adam_steps=2):
+    """One optimisation step of the reference loop (train.py:74-107): forward, L1 loss, backward, torch.optim.Adam with
+    the reference's hyper-parameters.  Records the loss, every gradient (sub-sample + statistics; full for the small
+    tensors) and the weights after `adam_steps` steps on the same batch."""
+    from types import SimpleNamespace
+    net = ref.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=s))
+    sd = deterministic_state(64, s, seed=wseed, flavor=flavor)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.train()
+    lr_in = torch.from_numpy(synthetic_lr(B, A, h, w, seed=iseed))
+    rng = np.random.Generator(np.random.PCG64([tseed, B, A, h, w, s]))
+    hr = torch.from_numpy(rng.random((B, 1, A * h * s, A * w * s), dtype=np.float32))
+    crit = ref.get_loss(None)
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=2e-4, betas=(0.9, 0.999), eps=1e-08, weight_decay=0)
+    rec = {"meta": np.array([A, s, B, h, w, wseed, iseed, tseed, adam_steps], dtype=np.int64), "flavor": np.array(flavor), "hr": hr.numpy()}
+    losses = []
+    for step in range(adam_steps):
+        opt.zero_grad()
+        loss = crit(net(lr_in), hr)
+        loss.backward()
+        losses.append(float(loss))
+        if step == 0:
+            for k, p in net.named_parameters():
+                g = p.grad.detach().contiguous().numpy().ravel()
+                rec[f"grad_{k}_sub"] = g[sub_indices(g.size)]
+                rec[f"grad_{k}_stats"] = stats(g)
+                if g.size <= 1024:
+                    rec[f"grad_{k}_full"] = g.copy()
+        opt.step()
+    rec["losses"] = np.array(losses, dtype=np.float64)
+    for k, p in net.named_parameters():
+        v = p.detach().contiguous().numpy().ravel()
+        rec[f"post_{k}_sub"] = v[sub_indices(v.size)]
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: losses {losses} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def main():
     torch.set_num_threads(8)
     ref = load_reference()
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    if "--train-only" in sys.argv:     # add the training fixtures without rewriting the others
+        train_case(ref, "train_a3_s2_b2_6x6", 3, 2, 2, 6, 6)
+        train_case(ref, "train_a2_s4_b1_8x5", 2, 4, 1, 8, 5)
+        return
     if "--wide-only" in sys.argv:      # add the h < w fixture without rewriting the others
         run_case(ref, "wide_a2_s2_b1_6x12", 2, 2, 1, 6, 12, full_taps=True)
         return
@@ -149,6 +191,8 @@ def main():
     # torch that runs here (>= 2.5) F.scaled_dot_product_attention returns 0 for those rows (older torch: NaN)
     run_case(ref, "wide_a2_s2_b1_6x12", 2, 2, 1, 6, 12, full_taps=True)
     run_case(ref, "cfg1_a5_s2_b1_32x32", 5, 2, 1, 32, 32, flavor="default")   # BASELINE configs[0]
+    train_case(ref, "train_a3_s2_b2_6x6", 3, 2, 2, 6, 6)
+    train_case(ref, "train_a2_s4_b1_8x5", 2, 4, 1, 8, 5)
     run_case(ref, "cfg2_a5_s4_b1_32x32", 5, 4, 1, 32, 32, flavor="default")   # one patch of configs[1]
 
 
