@@ -4,6 +4,10 @@ Inference (BASELINE configs 2, 4, 5) needs no data-path collective: light-field 
 (SURVEY.md 8e), so each rank owns a contiguous slice of the batch.  torch.distributed ("nccl" = RCCL on
 ROCm, "gloo" in the CPU tests) is only used for the barrier / max-over-ranks of the timing protocol and
 for gathering results where a caller wants them on one rank.
+
+Training (BASELINE config 3) has exactly one exchange per step: the sum of the flat gradient buffer
+(1.11 M floats, 4.5 MB) over the ranks -- ``sum_gradients_``; the division by the world size is folded into
+the Adam kernel (lft_amd/train.py:TrainStep).
 """
 from __future__ import annotations
 
@@ -50,3 +54,23 @@ def gather_patches(local: torch.Tensor, n_total: int) -> torch.Tensor:
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
     return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+
+
+def sum_gradients_(flat: torch.Tensor, group=None) -> float:
+    """In-place SUM all-reduce of the flat gradient buffer over the data-parallel ranks; returns the factor
+    (1 / world) that turns the sum of per-shard mean-loss gradients into the global-batch gradient (equal shards:
+    L1Loss is a mean over the local shard, reference LFT.py:272).  One collective per step.
+    With the gloo backend (CPU rehearsals, or several ranks sharing one GPU) device tensors go through the host."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 1.0
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world

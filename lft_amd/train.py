@@ -142,12 +142,8 @@ class TrainStep:
         self._tape = None
         self._scratch = torch.empty(1024 + 1, dtype=torch.float32, device=dev)
 
-    def world(self) -> int:
-        import torch.distributed as dist
-        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
-
     def step(self, lr_in: torch.Tensor, hr: torch.Tensor) -> torch.Tensor:
-        import torch.distributed as dist
+        from .dp import sum_gradients_
         dev = lr_in.device
         B, _, H, W = lr_in.shape
         h, w = H // self.A, W // self.A
@@ -164,13 +160,11 @@ class TrainStep:
             _lib.check(L.lft_l1_loss(out.data_ptr(), hr.data_ptr(), n, dout.data_ptr(), 1.0 / n, loss.data_ptr(),
                                      self._scratch.data_ptr(), stream), "lft_l1_loss")
             train_backward(self.params, lr_in, self._tape, dout, self.A, self.s, grads=self.flat_grads)
-            world = self.world()
-            if world > 1:
-                dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+            gscale = sum_gradients_(self.flat_grads, self.group)          # the step's only collective
             self.t += 1
             _lib.check(L.lft_adam_step(self.flat_params.data_ptr(), self.flat_grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                        self.flat_params.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.t,
-                                       1.0 / world, stream), "lft_adam_step")
+                                       gscale, stream), "lft_adam_step")
         self.net._packed = None            # the inference path must re-pack the new weights
         return loss.clone()
 

@@ -193,3 +193,21 @@ def test_autograd_surface_like_reference_train_py():
     before = {k: p.detach().clone() for k, p in net.named_parameters()}
     opt.step()
     assert all(not torch.equal(before[k], p) for k, p in net.named_parameters())
+
+
+def test_two_rank_dp_step_equals_single_rank(tmp_path):
+    """Two ranks (sharing the one GPU of the test box, gloo) with half the batch each == one rank with the whole batch:
+    the flat-gradient sum + 1/world inside Adam reproduces the global-batch step."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(__file__), "dp_train_worker.py")
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.run([sys.executable, worker, "2", one], check=True, env=env, timeout=300)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29611", worker, "2", two], check=True, env=env, timeout=300)
+    a, b = torch.load(one), torch.load(two)
+    # Adam normalises the step (~lr per weight per step), so compare displacements: 2 steps of 2e-4
+    d = (a["flat"] - b["flat"]).abs()
+    print(f"single vs 2-rank DP after 2 steps: max |dw| {float(d.max()):.2e}, mean {float(d.mean()):.2e}")
+    assert float(d.max()) <= 1.05 * 2 * 2e-4 and float(d.mean()) <= 2e-5
