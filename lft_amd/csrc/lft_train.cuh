@@ -7,44 +7,31 @@
 //                                       transposed weight strides and flipped taps -- their input gradients
 //   k_wgrad  dW = dY^T X                split over token chunks (deterministic two-stage reduction)
 // plus the small VALU kernels around them (LayerNorm, both attentions, activations, up-sampler tail).
-// Weights are read in place from the 78 parameter tensors (they change every step, so nothing is packed).
+// Weights change every step: at the start of a step both orientations (W for the forward, W^T for the input gradients)
+// are re-packed into fragment order by k_pack (9 MB, microseconds) so that every weight read is a coalesced 1 KiB piece.
 // All tensors are fp32 channels-last [token][channel]; token = ((b*V + v)*h + y)*w + x.
 #pragma once
 #include "lft_common.cuh"
 
 // ------------------------------------------------------------------------------------------
 // Generic linear / per-view 3x3 convolution on MFMA.
-//   Y[t][o] = act( sum_tap sum_i W[o*so + i*si + tap*st] * X[shift_tap(t)][i] ) (+ R[t][o])
+//   Y[t][o] = act( sum_tap sum_i W(o, i, tap) * X[shift_tap(t)][i] ) (+ R[t][o])
 // taps == 1: plain Linear.  taps == 9: tap -> (dy, dx) = (tap/3 - 1, tap%3 - 1), the source token is
 // (y + dy, x + dx) of the same view image (zero outside: per-view zero padding, reference LFT.py:24,28,167);
-// flip negates the offset, which together with swapped so/si turns the kernel into the convolution's input gradient.
+// flip negates the offset, which together with the transposed packing turns the kernel into the convolution's input gradient.
 // A wave owns 32 tokens x NT*32 output channels (blockIdx.y selects the channel group).
 // ------------------------------------------------------------------------------------------
 struct LinP {
     const float* X; int ldx;
-    const float* W; int so, si, st;
+    const float* Wp; int OT, KS;      // packed fragments (k_pack, natural k order): frag (tap, ot, ks) at ((tap*OT + ot)*KS + ks)
     const float* R; int ldr;          // optional: accumulator initialised with R (residual, or Y itself to accumulate)
     float* Y; int ldy;
-    int Ci, Co, taps, flip, act;      // act: 0 none, 1 relu, 2 leaky relu 0.2
+    int taps, flip, act;              // act: 0 none, 1 relu, 2 leaky relu 0.2
     int h, w;
     long long N;
 };
 
-template <bool CONTIG>
-LFT_DEV Frag<float> load_w_frag(const float* __restrict__ W, int o, int k, int so, int si, int base) {
-    Frag<float> f;
-    if constexpr (CONTIG) {                 // si == 1 and 16-byte aligned rows: two dwordx4
-        const float* p = W + (size_t)o * so + base + k;
-        f.lo = load4(p); f.hi = load4(p + 4);
-    } else {
-        const float* p = W + (size_t)o * so + base + (size_t)k * si;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { f.lo[j] = p[(size_t)j * si]; f.hi[j] = p[(size_t)(j + 4) * si]; }
-    }
-    return f;
-}
-
-template <int NT, bool CONTIG>
+template <int NT>
 __global__ __launch_bounds__(256) void k_lin(const LinP p) {
     __shared__ __attribute__((aligned(16))) char scr_all[4 * TileIO<NT, float>::BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, kh = lane >> 5;
@@ -52,7 +39,7 @@ __global__ __launch_bounds__(256) void k_lin(const LinP p) {
     const long long t0 = ((long long)blockIdx.x * 4 + wave) * 32;
     if (t0 >= p.N) return;
     const int nvalid = (int)min((long long)32, p.N - t0);
-    const int o0 = blockIdx.y * NT * 32;
+    const int ot0 = blockIdx.y * NT, o0 = ot0 * 32;
     const long long t = min(t0 + r, p.N - 1);
     const int hw = p.h * p.w;
     const int pix = (int)(t % hw), y = pix / p.w, x = pix - y * p.w;
@@ -64,13 +51,11 @@ __global__ __launch_bounds__(256) void k_lin(const LinP p) {
         if (p.taps == 9) { dy = tap / 3 - 1; dx = tap % 3 - 1; if (p.flip) { dy = -dy; dx = -dx; } }
         const bool ok = (t0 + r < p.N) && (y + dy >= 0) && (y + dy < p.h) && (x + dx >= 0) && (x + dx < p.w);
         const float* row = p.X + (ok ? (t + dy * p.w + dx) : t) * p.ldx + 8 * kh;
-        for (int k0 = 0; k0 < p.Ci; k0 += 16) {
-            const Frag<float> b = load_row8(row + k0, ok, 0.0f);
+        const int fbase = (tap * p.OT + ot0) * p.KS;
+        for (int ks = 0; ks < p.KS; ++ks) {
+            const Frag<float> b = load_row8(row + 16 * ks, ok, 0.0f);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const Frag<float> a = load_w_frag<CONTIG>(p.W, o0 + 32 * nt + r, k0 + 8 * kh, p.so, p.si, tap * p.st);
-                mma(a, b, acc[nt]);
-            }
+            for (int nt = 0; nt < NT; ++nt) mma(load_wfrag(p.Wp, fbase + nt * p.KS + ks, lane), b, acc[nt]);
         }
     }
     if (p.act) {
@@ -143,13 +128,23 @@ __global__ __launch_bounds__(64) void k_wgrad(const WgP p) {
             dst[(size_t)(o0 + acc_row(i, kh)) * p.so + (size_t)(i0 + 32 * ni + r) * p.si] = acc[ni][i];
 }
 
-// dst[i] (+)= sum_c part[c][i], chunks summed in index order (deterministic).
-__global__ void k_reduce(const float* __restrict__ part, int nch, long long n, long long stride, float* __restrict__ dst, int accumulate) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.0f;
-    for (int c = 0; c < nch; ++c) s += part[(long long)c * stride + i];
-    dst[i] = accumulate ? dst[i] + s : s;
+// dst[i] (+)= sum_c part[c*stride + i], in a fixed order (deterministic): block = 64 elements x 4 chunk lanes.
+__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ part, int nch, long long n, long long stride, float* __restrict__ dst, int accumulate) {
+    __shared__ float red[4][64];
+    const int xl = threadIdx.x & 63, yl = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + xl;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (i < n) {
+        int c = yl;
+        for (; c + 4 < nch; c += 8) { s0 += part[(long long)c * stride + i]; s1 += part[(long long)(c + 4) * stride + i]; }
+        if (c < nch) s0 += part[(long long)c * stride + i];
+    }
+    red[yl][xl] = s0 + s1;
+    __syncthreads();
+    if (yl == 0 && i < n) {
+        const float t = (red[0][xl] + red[1][xl]) + (red[2][xl] + red[3][xl]);
+        dst[i] = accumulate ? dst[i] + t : t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -452,40 +447,39 @@ __global__ __launch_bounds__(256) void k_win_attn(const float* __restrict__ Q, c
     const int pix = (int)(tok % hw);
     const long long img0 = tok - pix;
     const int y = pix / w, x = pix % w;
-    const float scale = 0.25f;                          // 1 / sqrt(16)
+    const float scale = 0.25f, scale2 = 0.25f * LFT_LOG2E;           // 1 / sqrt(16); softmax evaluated as 2^(s log2 e - m)
     const size_t off = (size_t)tok * 128 + head * 16;
     if (MODE == 0 || MODE == 1) {
         const int y0 = max(0, y - 2), y1 = min(h, y + 3), x0 = max(0, x - 2), x1 = min(min(h, x + 3), w);   // LFT.py:150-160 (sic)
         float q[16], kv[16], vv[16], dov[16];
         ld16(Q + off, q);
         if (MODE == 1) ld16(dO + off, dov);
-        float m = -INFINITY;
-        for (int ky = y0; ky < y1; ++ky)
-            for (int kx = x0; kx < x1; ++kx) {
-                ld16(K + (size_t)(img0 + ky * w + kx) * 128 + head * 16, kv);
-                m = fmaxf(m, scale * dot16(q, kv));
-            }
-        float l = 0.0f, D = 0.0f, o[16], a2[16];
+        // one pass, running maximum (K and V of a key are read once): all accumulators are linear in the weights
+        float m = -INFINITY, l = 0.0f, D = 0.0f, o[16], a2[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) { o[c] = 0.0f; a2[c] = 0.0f; }
         for (int ky = y0; ky < y1; ++ky)
+#pragma unroll 1
             for (int kx = x0; kx < x1; ++kx) {
                 const size_t ko = (size_t)(img0 + ky * w + kx) * 128 + head * 16;
                 ld16(K + ko, kv);
                 ld16(Vv + ko, vv);
-                const float pj = expf(scale * dot16(q, kv) - m);
-                l += pj;
+                const float sj = scale2 * dot16(q, kv);
+                const float mn = fmaxf(m, sj);
+                const float corr = fast_exp2(m - mn), pj = fast_exp2(sj - mn);     // first key: 2^(-inf) = 0
+                m = mn;
+                l = l * corr + pj;
                 if (MODE == 0) {
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) o[c] += pj * vv[c];
+                    for (int c = 0; c < 16; ++c) o[c] = o[c] * corr + pj * vv[c];
                 } else {
                     const float dp = dot16(dov, vv);
-                    D += pj * dp;
+                    D = D * corr + pj * dp;
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) { o[c] += pj * dp * kv[c]; a2[c] += pj * kv[c]; }
+                    for (int c = 0; c < 16; ++c) { o[c] = o[c] * corr + pj * dp * kv[c]; a2[c] = a2[c] * corr + pj * kv[c]; }
                 }
             }
-        const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+        const float inv = l > 0.0f ? 1.0f / l : 0.0f;                  // empty window (h < w): output 0, no gradient
         if (MODE == 0) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) o[c] *= inv;
@@ -496,7 +490,7 @@ __global__ __launch_bounds__(256) void k_win_attn(const float* __restrict__ Q, c
             for (int c = 0; c < 16; ++c) o[c] = scale * inv * (o[c] - D * a2[c]);
             st16(dQ + off, o);
             float* s3 = stats + ((size_t)tok * 8 + head) * 3;
-            s3[0] = l > 0.0f ? m : 0.0f; s3[1] = inv; s3[2] = D;
+            s3[0] = l > 0.0f ? m : 0.0f; s3[1] = inv; s3[2] = D;        // m in the log2 domain
         }
     } else {
         float kj[16], vj[16], qi[16], di[16], dk[16], dv[16];
@@ -504,15 +498,16 @@ __global__ __launch_bounds__(256) void k_win_attn(const float* __restrict__ Q, c
         ld16(Vv + off, vj);
 #pragma unroll
         for (int c = 0; c < 16; ++c) { dk[c] = 0.0f; dv[c] = 0.0f; }
-        if (x < h) {                                       // keys with x >= h are in nobody's window (the column bound uses h)
+        if (x < h) {                                                   // keys with x >= h are in nobody's window (the column bound uses h)
             for (int qy = max(0, y - 2); qy < min(h, y + 3); ++qy)
+#pragma unroll 1
                 for (int qx = max(0, x - 2); qx < min(w, x + 3); ++qx) {
                     const long long qt = img0 + qy * w + qx;
                     const size_t qo = (size_t)qt * 128 + head * 16;
                     ld16(Q + qo, qi);
                     ld16(dO + qo, di);
                     const float* s3 = stats + ((size_t)qt * 8 + head) * 3;
-                    const float pij = expf(scale * dot16(qi, kj) - s3[0]) * s3[1];
+                    const float pij = fast_exp2(scale2 * dot16(qi, kj) - s3[0]) * s3[1];
                     const float ds = pij * (dot16(di, vj) - s3[2]);
 #pragma unroll
                     for (int c = 0; c < 16; ++c) { dk[c] += ds * qi[c]; dv[c] += pij * di[c]; }

@@ -32,10 +32,57 @@ inline ParamInfo param_info(int s) {
     return pi;
 }
 
+// ---- packed weight views: every matrix the step multiplies by, in both orientations, as k_pack fragment streams ----
+enum { VW_CONV_F = 0, VW_CONV_B = 3, VW_LAYER0 = 6, VW_PER_LAYER = 24, VW_UP_F = VW_LAYER0 + 4 * VW_PER_LAYER, VW_UP_B, VW_COUNT };
+enum { MLP_F = 0, MLP_B, SIN_F, SQ_B, SK_B, SV_B, SOUT_F, SOUT_B, SFF1_F, SFF1_B, SFF2_F, SFF2_B, SLIN_F, SLIN_B,
+       AIN_F, AQK_B, AV_B, AOUT_F, AOUT_B, AFF1_F, AFF1_B, AFF2_F, AFF2_B };
+inline int vw(int l, int which) { return VW_LAYER0 + VW_PER_LAYER * l + which; }
+struct WView { size_t frag0 = 0; int OT = 0, KS = 0, taps = 0; };
+struct WViews { WView v[VW_COUNT]; size_t nfrags = 0; };
+
+// Enumerates the views in storage order.  P may be null (layout only).  out(n), in(k) are the VIEW's output / contraction
+// dims; element (n, k, tap) of the view is src[n*ld + k*kmul + kadd + tap*st].
+WViews build_views(const float* const* P, int s, std::vector<PackOp>* ops) {
+    WViews W;
+    auto add = [&](int id, const float* src, int O, int I, int taps, int ld, int kmul, int kadd, int st) {
+        WView& v = W.v[id];
+        v.frag0 = W.nfrags; v.OT = O / 32; v.KS = I / 16; v.taps = taps;
+        W.nfrags += (size_t)taps * v.OT * v.KS;
+        if (ops)
+            for (int t = 0; t < taps; ++t) ops->push_back(lin_op(src, 0, O, ld, 0, I / 16, 0, 1.0f, kmul, kadd + t * st));
+    };
+    auto fwd = [&](int id, const float* src, int O, int I, int row0 = 0) { add(id, src, O, I, 1, I, 1, row0 * I, 0); };
+    auto bwd = [&](int id, const float* src, int O, int I, int row0 = 0) { add(id, src, I, O, 1, 1, I, row0 * I, 0); };   // W^T of rows row0..row0+O
+    auto src = [&](int idx) { return P ? P[idx] : nullptr; };
+    for (int i = 0; i < 3; ++i) add(VW_CONV_F + i, src(P_CONV + i), 64, 64, 9, 576, 9, 0, 1);
+    for (int i = 0; i < 3; ++i) add(VW_CONV_B + i, src(P_CONV + i), 64, 64, 9, 9, 576, 0, 1);
+    for (int l = 0; l < kLayers; ++l) {
+        add(vw(l, MLP_F), src(pidx(l, S_MLP)), 128, 64, 9, 576, 9, 0, 1);
+        add(vw(l, MLP_B), src(pidx(l, S_MLP)), 64, 128, 9, 9, 576, 0, 1);
+        fwd(vw(l, SIN_F), src(pidx(l, S_INPROJ)), 384, 128);
+        bwd(vw(l, SQ_B), src(pidx(l, S_INPROJ)), 128, 128, 0);
+        bwd(vw(l, SK_B), src(pidx(l, S_INPROJ)), 128, 128, 128);
+        bwd(vw(l, SV_B), src(pidx(l, S_INPROJ)), 128, 128, 256);
+        fwd(vw(l, SOUT_F), src(pidx(l, S_OUT)), 128, 128); bwd(vw(l, SOUT_B), src(pidx(l, S_OUT)), 128, 128);
+        fwd(vw(l, SFF1_F), src(pidx(l, S_FF1)), 256, 128); bwd(vw(l, SFF1_B), src(pidx(l, S_FF1)), 256, 128);
+        fwd(vw(l, SFF2_F), src(pidx(l, S_FF2)), 128, 256); bwd(vw(l, SFF2_B), src(pidx(l, S_FF2)), 128, 256);
+        fwd(vw(l, SLIN_F), src(pidx(l, S_LIN)), 64, 128); bwd(vw(l, SLIN_B), src(pidx(l, S_LIN)), 64, 128);
+        fwd(vw(l, AIN_F), src(pidx(l, A_INPROJ)), 192, 64);
+        bwd(vw(l, AQK_B), src(pidx(l, A_INPROJ)), 128, 64, 0);
+        bwd(vw(l, AV_B), src(pidx(l, A_INPROJ)), 64, 64, 128);
+        fwd(vw(l, AOUT_F), src(pidx(l, A_OUT)), 64, 64); bwd(vw(l, AOUT_B), src(pidx(l, A_OUT)), 64, 64);
+        fwd(vw(l, AFF1_F), src(pidx(l, A_FF1)), 128, 64); bwd(vw(l, AFF1_B), src(pidx(l, A_FF1)), 128, 64);
+        fwd(vw(l, AFF2_F), src(pidx(l, A_FF2)), 64, 128); bwd(vw(l, AFF2_B), src(pidx(l, A_FF2)), 64, 128);
+    }
+    fwd(VW_UP_F, src(P_UP0), 64 * s * s, 64); bwd(VW_UP_B, src(P_UP0), 64 * s * s, 64);
+    return W;
+}
+
 // ---- tape: everything the backward pass re-reads (floats, offsets in floats) ----
 struct AngTape { size_t n, qk, v, o, t1, m, hdn, y; };
 struct SpaTape { size_t petok, tok, n, q, k, v, o, t1, m, hdn, t2, y; };
 struct TrainLayout {
+    size_t wp;                                   // packed weight views (build_views order), 512 floats per fragment
     size_t pe_ang, pe_spa, x0, c1, c2, c3, feat;
     AngTape ang[kLayers];
     SpaTape spa[kLayers];
@@ -44,7 +91,7 @@ struct TrainLayout {
     size_t g64[5], g128[5], g256, gu, stats, dpetok, part, pgb;
     size_t part_floats, total;                   // total in floats
 };
-constexpr int kWgChunks = 128;                   // token chunks of a weight-gradient launch
+constexpr int kWgChunks = 512;                   // token chunks of a weight-gradient launch
 constexpr int kLnBlocks = 512;                   // workgroups (= partial rows) of a LayerNorm backward
 constexpr int kTailWaves = 2048;                 // waves of the up-sampler / conv0 weight-gradient kernels
 
@@ -53,6 +100,7 @@ TrainLayout train_layout(const Dims& d) {
     size_t o = 0;
     auto take = [&](size_t floats) { size_t r = o; o += (floats + 63) & ~(size_t)63; return r; };
     const size_t n = (size_t)d.ntok, ss = (size_t)d.s * d.s;
+    T.wp = take(build_views(nullptr, d.s, nullptr).nfrags * 512);
     T.pe_ang = take((size_t)d.V * 64); T.pe_spa = take((size_t)d.hw * 64);
     T.x0 = take(n * 64); T.c1 = take(n * 64); T.c2 = take(n * 64); T.c3 = take(n * 64); T.feat = take(n * 64);
     for (int l = 0; l < kLayers; ++l) {
@@ -83,40 +131,34 @@ struct TrainCtx {
     const Dims& d;
     float* tp;                 // tape base
     const TrainLayout& T;
+    const WViews& W;
     hipStream_t st;
     float* F(size_t off) const { return tp + off; }
 };
 
-int run_lin(const TrainCtx& c, const float* X, int ldx, const float* W, int so, int si, int st_, int Ci, int Co, int taps, int flip,
-            int act, const float* R, int ldr, float* Y, int ldy, long long N, int h, int w) {
-    if (Ci % 16 || Co % 64) return fail(LFT_ERR_ARG, "run_lin: Ci %d / Co %d not supported", Ci, Co);
-    LinP p{X, ldx, W, so, si, st_, R, ldr, Y, ldy, Ci, Co, taps, flip, act, h, w, N};
-    const bool contig = si == 1 && taps == 1 && so % 4 == 0;
+// Y[N][ldy cols o0..] = act(X W(view)^T) (+R).  ot0 / nOT select a block of the view's output tiles (taps == 1 only).
+int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int ldx, int flip, int act, const float* R, int ldr,
+            float* Y, int ldy, long long N) {
+    const WView& v = c.W.v[view];
+    if (nOT <= 0) nOT = v.OT;
+    if (nOT % 2 || (v.taps != 1 && (ot0 || nOT != v.OT))) return fail(LFT_ERR_ARG, "run_lin: bad tile block (view %d)", view);
+    LinP p{X, ldx, c.F(c.T.wp) + (v.frag0 + (size_t)ot0 * v.KS) * 512, v.OT, v.KS, R, ldr, Y, ldy, v.taps, flip, act, c.d.h, c.d.w, N};
     const unsigned gx = (unsigned)((N + 127) / 128);
-    if (Co % 128 == 0) {
-        const dim3 g(gx, (unsigned)(Co / 128));
-        if (contig) k_lin<4, true><<<g, 256, 0, c.st>>>(p); else k_lin<4, false><<<g, 256, 0, c.st>>>(p);
-    } else {
-        const dim3 g(gx, (unsigned)(Co / 64));
-        if (contig) k_lin<2, true><<<g, 256, 0, c.st>>>(p); else k_lin<2, false><<<g, 256, 0, c.st>>>(p);
-    }
+    if (nOT % 4 == 0) k_lin<4><<<dim3(gx, (unsigned)(nOT / 4)), 256, 0, c.st>>>(p);
+    else k_lin<2><<<dim3(gx, (unsigned)(nOT / 2)), 256, 0, c.st>>>(p);
     LFT_LAUNCH_OK("k_lin");
     return 0;
 }
-// plain Linear: Y = act(X W^T) (+R), W [Co][Ci] row-major
-int lin_fwd(const TrainCtx& c, const float* X, const float* W, int Ci, int Co, int act, const float* R, float* Y, long long N) {
-    return run_lin(c, X, Ci, W, Ci, 1, 0, Ci, Co, 1, 0, act, R, Co, Y, Co, N, c.d.h, c.d.w);
+// Linear / conv forward through view `view` (all of its output rows, or tiles [ot0, ot0 + nOT)): Y = act(X W^T) (+R)
+int lin_fwd(const TrainCtx& c, int view, const float* X, int act, const float* R, float* Y, long long N, int ot0 = 0, int nOT = 0) {
+    const WView& v = c.W.v[view];
+    const int Co = (nOT > 0 ? nOT : v.OT) * 32;
+    return run_lin(c, view, ot0, nOT, X, v.KS * 16, 0, act, R, Co, Y, Co, N);
 }
-// its input gradient: dX = dY W (+R), i.e. a Linear with the transposed weight
-int lin_bwd(const TrainCtx& c, const float* dY, const float* W, int Ci, int Co, const float* R, float* dX, long long N) {
-    return run_lin(c, dY, Co, W, 1, Ci, 0, Co, Ci, 1, 0, 0, R, Ci, dX, Ci, N, c.d.h, c.d.w);
-}
-// per-view 3x3 conv, weight [Co][Ci][3][3] (the unfold-MLP weight [Co][Ci*9] has the same element order, LFT.py:167)
-int conv_fwd(const TrainCtx& c, const float* X, const float* W, int Ci, int Co, int act, const float* R, float* Y, long long N) {
-    return run_lin(c, X, Ci, W, Ci * 9, 9, 1, Ci, Co, 9, 0, act, R, Co, Y, Co, N, c.d.h, c.d.w);
-}
-int conv_bwd(const TrainCtx& c, const float* dY, const float* W, int Ci, int Co, const float* R, float* dX, long long N) {
-    return run_lin(c, dY, Co, W, 9, Ci * 9, 1, Co, Ci, 9, 1, 0, R, Ci, dX, Ci, N, c.d.h, c.d.w);
+// Input gradient through a transposed view: dX = dY W (+R); 3x3 convs flip their taps
+int lin_bwd(const TrainCtx& c, int view, const float* dY, const float* R, float* dX, long long N) {
+    const WView& v = c.W.v[view];
+    return run_lin(c, view, 0, 0, dY, v.KS * 16, 1, 0, R, v.OT * 32, dX, v.OT * 32, N);
 }
 // weight gradient of either: dW (+)= dY^T X  (taps = 1 or 9)
 int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, int taps, float* dW, int accumulate, long long N) {
@@ -135,7 +177,7 @@ int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, in
         k_wgrad<2><<<dim3((unsigned)nch, (unsigned)(Co / 32 * p.igroups), (unsigned)taps), 64, 0, c.st>>>(p);
     }
     LFT_LAUNCH_OK("k_wgrad");
-    k_reduce<<<blocks_for(wsize, 256), 256, 0, c.st>>>(c.F(c.T.part), nch, wsize, wsize, dW, accumulate);
+    k_reduce<<<blocks_for(wsize, 64), 256, 0, c.st>>>(c.F(c.T.part), nch, wsize, wsize, dW, accumulate);
     LFT_LAUNCH_OK("k_reduce");
     return 0;
 }
@@ -153,9 +195,9 @@ int ln_bwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, 
     else k_ln_bwd<128><<<nb, 256, 0, c.st>>>(X, pe, mode, g, dY, add, out, c.F(c.T.pgb), N, c.d.hw, c.d.V);
     LFT_LAUNCH_OK("k_ln_bwd");
     // pgb rows are [dgamma(C) | dbeta(C)]
-    k_reduce<<<blocks_for(C, 256), 256, 0, c.st>>>(c.F(c.T.pgb), nb, C, 2 * C, dgamma, 0);
+    k_reduce<<<blocks_for(C, 64), 256, 0, c.st>>>(c.F(c.T.pgb), nb, C, 2 * C, dgamma, 0);
     LFT_LAUNCH_OK("k_reduce");
-    k_reduce<<<blocks_for(C, 256), 256, 0, c.st>>>(c.F(c.T.pgb) + C, nb, C, 2 * C, dbeta, 0);
+    k_reduce<<<blocks_for(C, 64), 256, 0, c.st>>>(c.F(c.T.pgb) + C, nb, C, 2 * C, dbeta, 0);
     LFT_LAUNCH_OK("k_reduce");
     return 0;
 }
@@ -188,57 +230,58 @@ int ang_attn(const TrainCtx& c, const float* QK, const float* Vv, float* O, cons
 // ---------------------------------------------------------------------------- forward with tape
 int train_forward(const float* const* P, const float* lr, float* out, float* tape, const Dims& d, hipStream_t st) {
     const TrainLayout T = train_layout(d);
-    const TrainCtx c{d, tape, T, st};
+    std::vector<PackOp> ops;
+    const WViews WV = build_views(P, d.s, &ops);
+    const TrainCtx c{d, tape, T, WV, st};
     const long long N = d.ntok;
-    const int nimg = d.B * d.V, ss = d.s * d.s;
+    const int nimg = d.B * d.V;
     int rc;
 #define TRY(x) do { if ((rc = (x))) return rc; } while (0)
+    TRY(run_pack<float>(ops, c.F(T.wp), (int)WV.nfrags, st));       // both orientations of every matrix, for this step's weights
     k_pe_plain<<<blocks_for(std::max(d.V, d.hw) * 64, 256), 256, 0, st>>>(c.F(T.pe_ang), c.F(T.pe_spa), d.V, d.h, d.w);
     LFT_LAUNCH_OK("k_pe_plain");
     // conv_init0, conv_init + residual (LFT.py:65-66)
     k_conv0<float><<<dim3((unsigned)((d.hw + 31) / 32), (unsigned)nimg), 256, 0, st>>>(lr, P[P_CONV0], c.F(T.x0), d.B, d.A, d.h, d.w);
     LFT_LAUNCH_OK("k_conv0");
-    TRY(conv_fwd(c, c.F(T.x0), P[P_CONV + 0], 64, 64, 2, nullptr, c.F(T.c1), N));
-    TRY(conv_fwd(c, c.F(T.c1), P[P_CONV + 1], 64, 64, 2, nullptr, c.F(T.c2), N));
-    TRY(conv_fwd(c, c.F(T.c2), P[P_CONV + 2], 64, 64, 2, nullptr, c.F(T.c3), N));
+    TRY(lin_fwd(c, VW_CONV_F + 0, c.F(T.x0), 2, nullptr, c.F(T.c1), N));
+    TRY(lin_fwd(c, VW_CONV_F + 1, c.F(T.c1), 2, nullptr, c.F(T.c2), N));
+    TRY(lin_fwd(c, VW_CONV_F + 2, c.F(T.c2), 2, nullptr, c.F(T.c3), N));
     LFT_HIP_OK(hipMemcpyAsync(c.F(T.feat), c.F(T.c3), (size_t)N * 64 * 4, hipMemcpyDeviceToDevice, st));
     TRY(add_to(c, c.F(T.feat), c.F(T.x0), N * 64));
     const float* x = c.F(T.feat);
     for (int l = 0; l < kLayers; ++l) {
         // ---- AngTrans (LFT.py:225-238) ----
         const AngTape& a = T.ang[l];
-        const float* Win = P[pidx(l, A_INPROJ)];
         TRY(ln_fwd(c, 64, x, c.F(T.pe_ang), 1, P[pidx(l, A_N1W)], P[pidx(l, A_N1B)], c.F(a.n), N));
-        TRY(lin_fwd(c, c.F(a.n), Win, 64, 128, 0, nullptr, c.F(a.qk), N));                 // Q | K from the normed tokens
-        TRY(lin_fwd(c, x, Win + 128 * 64, 64, 64, 0, nullptr, c.F(a.v), N));               // V from the raw tokens
+        TRY(lin_fwd(c, vw(l, AIN_F), c.F(a.n), 0, nullptr, c.F(a.qk), N, 0, 4));                 // Q | K from the normed tokens
+        TRY(lin_fwd(c, vw(l, AIN_F), x, 0, nullptr, c.F(a.v), N, 4, 2));               // V from the raw tokens
         TRY(ang_attn<false>(c, c.F(a.qk), c.F(a.v), c.F(a.o), nullptr, nullptr, nullptr));
-        TRY(lin_fwd(c, c.F(a.o), P[pidx(l, A_OUT)], 64, 64, 0, x, c.F(a.t1), N));
+        TRY(lin_fwd(c, vw(l, AOUT_F), c.F(a.o), 0, x, c.F(a.t1), N));
         TRY(ln_fwd(c, 64, c.F(a.t1), nullptr, 0, P[pidx(l, A_N2W)], P[pidx(l, A_N2B)], c.F(a.m), N));
-        TRY(lin_fwd(c, c.F(a.m), P[pidx(l, A_FF1)], 64, 128, 1, nullptr, c.F(a.hdn), N));
-        TRY(lin_fwd(c, c.F(a.hdn), P[pidx(l, A_FF2)], 128, 64, 0, c.F(a.t1), c.F(a.y), N));
+        TRY(lin_fwd(c, vw(l, AFF1_F), c.F(a.m), 1, nullptr, c.F(a.hdn), N));
+        TRY(lin_fwd(c, vw(l, AFF2_F), c.F(a.hdn), 0, c.F(a.t1), c.F(a.y), N));
         x = c.F(a.y);
         // ---- SpaTrans (LFT.py:176-191) ----
         const SpaTape& sp = T.spa[l];
-        const float* Wsp = P[pidx(l, S_INPROJ)];
-        TRY(conv_fwd(c, x, P[pidx(l, S_MLP)], 64, 128, 0, nullptr, c.F(sp.tok), N));
-        TRY(conv_fwd(c, c.F(T.pe_spa), P[pidx(l, S_MLP)], 64, 128, 0, nullptr, c.F(sp.petok), d.hw));   // LFT.py:180
+        TRY(lin_fwd(c, vw(l, MLP_F), x, 0, nullptr, c.F(sp.tok), N));
+        TRY(lin_fwd(c, vw(l, MLP_F), c.F(T.pe_spa), 0, nullptr, c.F(sp.petok), d.hw));   // LFT.py:180
         TRY(ln_fwd(c, 128, c.F(sp.tok), c.F(sp.petok), 2, P[pidx(l, S_N1W)], P[pidx(l, S_N1B)], c.F(sp.n), N));
-        TRY(lin_fwd(c, c.F(sp.n), Wsp, 128, 128, 0, nullptr, c.F(sp.q), N));
-        TRY(lin_fwd(c, c.F(sp.n), Wsp + 128 * 128, 128, 128, 0, nullptr, c.F(sp.k), N));
-        TRY(lin_fwd(c, c.F(sp.tok), Wsp + 256 * 128, 128, 128, 0, nullptr, c.F(sp.v), N));
+        TRY(lin_fwd(c, vw(l, SIN_F), c.F(sp.n), 0, nullptr, c.F(sp.q), N, 0, 4));
+        TRY(lin_fwd(c, vw(l, SIN_F), c.F(sp.n), 0, nullptr, c.F(sp.k), N, 4, 4));
+        TRY(lin_fwd(c, vw(l, SIN_F), c.F(sp.tok), 0, nullptr, c.F(sp.v), N, 8, 4));
         k_win_attn<0><<<blocks_for(N * 8, 256), 256, 0, st>>>(c.F(sp.q), c.F(sp.k), c.F(sp.v), c.F(sp.o), nullptr, nullptr, nullptr,
                                                             nullptr, nullptr, N, d.h, d.w);
         LFT_LAUNCH_OK("k_win_attn");
-        TRY(lin_fwd(c, c.F(sp.o), P[pidx(l, S_OUT)], 128, 128, 0, c.F(sp.tok), c.F(sp.t1), N));
+        TRY(lin_fwd(c, vw(l, SOUT_F), c.F(sp.o), 0, c.F(sp.tok), c.F(sp.t1), N));
         TRY(ln_fwd(c, 128, c.F(sp.t1), nullptr, 0, P[pidx(l, S_N2W)], P[pidx(l, S_N2B)], c.F(sp.m), N));
-        TRY(lin_fwd(c, c.F(sp.m), P[pidx(l, S_FF1)], 128, 256, 1, nullptr, c.F(sp.hdn), N));
-        TRY(lin_fwd(c, c.F(sp.hdn), P[pidx(l, S_FF2)], 256, 128, 0, c.F(sp.t1), c.F(sp.t2), N));
+        TRY(lin_fwd(c, vw(l, SFF1_F), c.F(sp.m), 1, nullptr, c.F(sp.hdn), N));
+        TRY(lin_fwd(c, vw(l, SFF2_F), c.F(sp.hdn), 0, c.F(sp.t1), c.F(sp.t2), N));
         const bool last = l == kLayers - 1;                                               // + global skip, LFT.py:76
-        TRY(lin_fwd(c, c.F(sp.t2), P[pidx(l, S_LIN)], 128, 64, 0, last ? c.F(T.feat) : nullptr, last ? c.F(T.body) : c.F(sp.y), N));
+        TRY(lin_fwd(c, vw(l, SLIN_F), c.F(sp.t2), 0, last ? c.F(T.feat) : nullptr, last ? c.F(T.body) : c.F(sp.y), N));
         x = last ? c.F(T.body) : c.F(sp.y);
     }
     // ---- up-sampler + bicubic skip (LFT.py:79-81) ----
-    TRY(lin_fwd(c, c.F(T.body), P[P_UP0], 64, 64 * ss, 2, nullptr, c.F(T.act), N));
+    TRY(lin_fwd(c, VW_UP_F, c.F(T.body), 2, nullptr, c.F(T.act), N));
     launch_assemble(lr, nullptr, c.F(T.skip), d.B, d.A, d.h, d.w, d.s, 0, st);
     LFT_LAUNCH_OK("k_assemble");
     const long long npx = (long long)d.B * d.A * d.h * d.s * d.A * d.w * d.s;
@@ -250,7 +293,8 @@ int train_forward(const float* const* P, const float* lr, float* out, float* tap
 // ---------------------------------------------------------------------------- backward
 int train_backward(const float* const* P, const float* lr, float* tape, const float* dout, float* G, const Dims& d, hipStream_t st) {
     const TrainLayout T = train_layout(d);
-    const TrainCtx c{d, tape, T, st};
+    const WViews WV = build_views(nullptr, d.s, nullptr);            // packed by this step's lft_train_forward
+    const TrainCtx c{d, tape, T, WV, st};
     const ParamInfo pi = param_info(d.s);
     const long long N = d.ntok;
     const int ss = d.s * d.s, nimg = d.B * d.V;
@@ -264,10 +308,10 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
         const long long nitems = N * ss, per = (nitems + kTailWaves - 1) / kTailWaves;
         k_up_conv_bwd<<<kTailWaves / 4, 256, 0, st>>>(c.F(T.act), P[P_UP3], dout, c.F(T.gu), c.F(T.part), d.B, d.A, d.h, d.w, d.s, per);
         LFT_LAUNCH_OK("k_up_conv_bwd");
-        k_reduce<<<blocks_for(576, 256), 256, 0, st>>>(c.F(T.part), kTailWaves, 576, 576, g(P_UP3), 0);
+        k_reduce<<<blocks_for(576, 64), 256, 0, st>>>(c.F(T.part), kTailWaves, 576, 576, g(P_UP3), 0);
         LFT_LAUNCH_OK("k_reduce");
         TRY(wgrad(c, c.F(T.gu), 64 * ss, c.F(T.body), 64, 1, g(P_UP0), 0, N));
-        TRY(lin_bwd(c, c.F(T.gu), P[P_UP0], 64, 64 * ss, nullptr, gskip, N));          // d body = d y3 = d feat (global skip)
+        TRY(lin_bwd(c, VW_UP_B, c.F(T.gu), nullptr, gskip, N));          // d body = d y3 = d feat (global skip)
     }
     const float* dy = gskip;
     for (int l = kLayers - 1; l >= 0; --l) {
@@ -275,18 +319,17 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
         {
             const SpaTape& sp = T.spa[l];
             const float* xin = c.F(T.ang[l].y);
-            const float* Wsp = P[pidx(l, S_INPROJ)];
             float* gin = g(pidx(l, S_INPROJ));
             TRY(wgrad(c, dy, 64, c.F(sp.t2), 128, 1, g(pidx(l, S_LIN)), 0, N));
-            TRY(lin_bwd(c, dy, P[pidx(l, S_LIN)], 128, 64, nullptr, h0, N));                         // d t2
+            TRY(lin_bwd(c, vw(l, SLIN_B), dy, nullptr, h0, N));                         // d t2
             TRY(wgrad(c, h0, 128, c.F(sp.hdn), 256, 1, g(pidx(l, S_FF2)), 0, N));
-            TRY(lin_bwd(c, h0, P[pidx(l, S_FF2)], 256, 128, nullptr, g256, N));                      // d hdn
+            TRY(lin_bwd(c, vw(l, SFF2_B), h0, nullptr, g256, N));                      // d hdn
             TRY(act_bwd(c, g256, c.F(sp.hdn), g256, N * 256, 1));
             TRY(wgrad(c, g256, 256, c.F(sp.m), 128, 1, g(pidx(l, S_FF1)), 0, N));
-            TRY(lin_bwd(c, g256, P[pidx(l, S_FF1)], 128, 256, nullptr, h1, N));                      // d m
+            TRY(lin_bwd(c, vw(l, SFF1_B), g256, nullptr, h1, N));                      // d m
             TRY(ln_bwd(c, 128, c.F(sp.t1), nullptr, 0, P[pidx(l, S_N2W)], h1, h0, h0, g(pidx(l, S_N2W)), g(pidx(l, S_N2B)), N));   // h0 = d t1
             TRY(wgrad(c, h0, 128, c.F(sp.o), 128, 1, g(pidx(l, S_OUT)), 0, N));
-            TRY(lin_bwd(c, h0, P[pidx(l, S_OUT)], 128, 128, nullptr, h1, N));                        // h1 = d O
+            TRY(lin_bwd(c, vw(l, SOUT_B), h0, nullptr, h1, N));                        // h1 = d O
             k_win_attn<1><<<blocks_for(N * 8, 256), 256, 0, st>>>(c.F(sp.q), c.F(sp.k), c.F(sp.v), nullptr, h1, h2, nullptr, nullptr,
                                                                 c.F(T.stats), N, d.h, d.w);          // h2 = dQ
             LFT_LAUNCH_OK("k_win_attn");
@@ -294,11 +337,11 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
                                                                 c.F(T.stats), N, d.h, d.w);          // h3 = dK, h4 = dV
             LFT_LAUNCH_OK("k_win_attn");
             TRY(wgrad(c, h4, 128, c.F(sp.tok), 128, 1, gin + 256 * 128, 0, N));
-            TRY(lin_bwd(c, h4, Wsp + 256 * 128, 128, 128, h0, h0, N));                               // d tok += dV Wv
+            TRY(lin_bwd(c, vw(l, SV_B), h4, h0, h0, N));                               // d tok += dV Wv
             TRY(wgrad(c, h2, 128, c.F(sp.n), 128, 1, gin, 0, N));
             TRY(wgrad(c, h3, 128, c.F(sp.n), 128, 1, gin + 128 * 128, 0, N));
-            TRY(lin_bwd(c, h2, Wsp, 128, 128, nullptr, h1, N));
-            TRY(lin_bwd(c, h3, Wsp + 128 * 128, 128, 128, h1, h1, N));                               // h1 = d n
+            TRY(lin_bwd(c, vw(l, SQ_B), h2, nullptr, h1, N));
+            TRY(lin_bwd(c, vw(l, SK_B), h3, h1, h1, N));                               // h1 = d n
             TRY(ln_bwd(c, 128, c.F(sp.tok), c.F(sp.petok), 2, P[pidx(l, S_N1W)], h1, nullptr, h2, g(pidx(l, S_N1W)), g(pidx(l, S_N1B)), N));  // h2 = d(tok+pe)
             k_sum_images<<<blocks_for((long long)d.hw * 128, 256), 256, 0, st>>>(h2, nimg, (long long)d.hw * 128, c.F(T.dpetok));
             LFT_LAUNCH_OK("k_sum_images");
@@ -307,27 +350,26 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
             {   // the position tokens are MLP(unfold(PE)) too (LFT.py:180): one more image of N = hw tokens
                 TRY(wgrad(c, c.F(T.dpetok), 128, c.F(T.pe_spa), 64, 9, g(pidx(l, S_MLP)), 1, d.hw));
             }
-            TRY(conv_bwd(c, h0, P[pidx(l, S_MLP)], 64, 128, nullptr, ga, N));                        // ga = d x_in
+            TRY(lin_bwd(c, vw(l, MLP_B), h0, nullptr, ga, N));                        // ga = d x_in
         }
         // ================= AngTrans backward: ga -> gb =================
         {
             const AngTape& a = T.ang[l];
             const float* xin = l == 0 ? c.F(T.feat) : c.F(T.spa[l - 1].y);
-            const float* Win = P[pidx(l, A_INPROJ)];
             float* gin = g(pidx(l, A_INPROJ));
             TRY(wgrad(c, ga, 64, c.F(a.hdn), 128, 1, g(pidx(l, A_FF2)), 0, N));
-            TRY(lin_bwd(c, ga, P[pidx(l, A_FF2)], 128, 64, nullptr, h0, N));                         // d hdn
+            TRY(lin_bwd(c, vw(l, AFF2_B), ga, nullptr, h0, N));                         // d hdn
             TRY(act_bwd(c, h0, c.F(a.hdn), h0, N * 128, 1));
             TRY(wgrad(c, h0, 128, c.F(a.m), 64, 1, g(pidx(l, A_FF1)), 0, N));
-            TRY(lin_bwd(c, h0, P[pidx(l, A_FF1)], 64, 128, nullptr, t64a, N));                       // d m
+            TRY(lin_bwd(c, vw(l, AFF1_B), h0, nullptr, t64a, N));                       // d m
             TRY(ln_bwd(c, 64, c.F(a.t1), nullptr, 0, P[pidx(l, A_N2W)], t64a, ga, gb, g(pidx(l, A_N2W)), g(pidx(l, A_N2B)), N));   // gb = d t1
             TRY(wgrad(c, gb, 64, c.F(a.o), 64, 1, g(pidx(l, A_OUT)), 0, N));
-            TRY(lin_bwd(c, gb, P[pidx(l, A_OUT)], 64, 64, nullptr, t64a, N));                        // d o
+            TRY(lin_bwd(c, vw(l, AOUT_B), gb, nullptr, t64a, N));                        // d o
             TRY(ang_attn<true>(c, c.F(a.qk), c.F(a.v), nullptr, t64a, h0, t64b));                    // h0 = dQK, t64b = dV
             TRY(wgrad(c, t64b, 64, xin, 64, 1, gin + 128 * 64, 0, N));
-            TRY(lin_bwd(c, t64b, Win + 128 * 64, 64, 64, gb, gb, N));                                // d x += dV Wv
+            TRY(lin_bwd(c, vw(l, AV_B), t64b, gb, gb, N));                                // d x += dV Wv
             TRY(wgrad(c, h0, 128, c.F(a.n), 64, 1, gin, 0, N));
-            TRY(lin_bwd(c, h0, Win, 64, 128, nullptr, t64a, N));                                     // d n
+            TRY(lin_bwd(c, vw(l, AQK_B), h0, nullptr, t64a, N));                                     // d n
             TRY(ln_bwd(c, 64, xin, c.F(T.pe_ang), 1, P[pidx(l, A_N1W)], t64a, gb, gb, g(pidx(l, A_N1W)), g(pidx(l, A_N1B)), N));
         }
         dy = gb;
@@ -337,18 +379,18 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
     TRY(add_to(c, gb, gskip, N * 64));
     TRY(act_bwd(c, gb, c.F(T.c3), ga, N * 64, 2));                                                   // d z3
     TRY(wgrad(c, ga, 64, c.F(T.c2), 64, 9, g(P_CONV + 2), 0, N));
-    TRY(conv_bwd(c, ga, P[P_CONV + 2], 64, 64, nullptr, gskip, N));                                  // d c2
+    TRY(lin_bwd(c, VW_CONV_B + 2, ga, nullptr, gskip, N));                                  // d c2
     TRY(act_bwd(c, gskip, c.F(T.c2), gskip, N * 64, 2));
     TRY(wgrad(c, gskip, 64, c.F(T.c1), 64, 9, g(P_CONV + 1), 0, N));
-    TRY(conv_bwd(c, gskip, P[P_CONV + 1], 64, 64, nullptr, ga, N));                                  // d c1
+    TRY(lin_bwd(c, VW_CONV_B + 1, gskip, nullptr, ga, N));                                  // d c1
     TRY(act_bwd(c, ga, c.F(T.c1), ga, N * 64, 2));
     TRY(wgrad(c, ga, 64, c.F(T.x0), 64, 9, g(P_CONV + 0), 0, N));
-    TRY(conv_bwd(c, ga, P[P_CONV + 0], 64, 64, gb, gb, N));                                          // d x0 = d feat + conv path
+    TRY(lin_bwd(c, VW_CONV_B + 0, ga, gb, gb, N));                                          // d x0 = d feat + conv path
     {
         const long long per = (N + kTailWaves - 1) / kTailWaves;
         k_conv0_wgrad<<<kTailWaves / 4, 256, 0, st>>>(gb, lr, c.F(T.part), d.B, d.A, d.h, d.w, per);
         LFT_LAUNCH_OK("k_conv0_wgrad");
-        k_reduce<<<blocks_for(576, 256), 256, 0, st>>>(c.F(T.part), kTailWaves, 576, 576, g(P_CONV0), 0);
+        k_reduce<<<blocks_for(576, 64), 256, 0, st>>>(c.F(T.part), kTailWaves, 576, 576, g(P_CONV0), 0);
         LFT_LAUNCH_OK("k_reduce");
     }
 #undef TRY
