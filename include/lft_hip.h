@@ -116,6 +116,15 @@ int lft_l1_loss(const float* sr, const float* hr, long long n, float* dsr, float
 int lft_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                   int step, float gscale, void* stream);
 
+/* ---- per-view quality metrics (reference utils/utils.py:56-88 cal_metrics, which calls scikit-image) ----
+ * label, out: fp32 mosaics [B,1,A*h,A*w]; psnr, ssim: fp32 [B*A*A] in (b, u, v) order.  PSNR = 10 log10(R^2 / MSE) with
+ * R = 1 when min(label view) >= 0 else 2; SSIM = mean over the view minus a 5-pixel border of the Gaussian-window
+ * (sigma 1.5, 11x11, sample covariance, K1 0.01, K2 0.03) SSIM map with data range `ssim_range` (2 reproduces the
+ * scikit-image releases contemporary with the reference; 1 is the physical range).  fp64 accumulation. */
+int lft_view_metrics_scratch_bytes(int B, int A, int h, int w, size_t* out_bytes);
+int lft_view_metrics(const float* label, const float* out, int B, int A, int h, int w, float ssim_range, float* psnr, float* ssim,
+                     void* scratch, void* stream);
+
 /* Debug aid: a single conv_init[which] launch (with_res: add `res`; extra_lds: pad the LDS request). */
 int lft_debug_conv64(const void* packed, int which, int with_res, const void* in, const void* res, void* out,
                      int B, int A, int h, int w, int s, int prec, int extra_lds, void* stream);

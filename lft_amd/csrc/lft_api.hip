@@ -3,6 +3,7 @@
 #include "../../include/lft_hip.h"
 #include "lft_kernels_a.cuh"
 #include "lft_kernels_b.cuh"
+#include "lft_metrics.cuh"
 
 #include <cstdarg>
 #include <cstdio>
@@ -594,6 +595,27 @@ int lft_mfma_selftest(const float* Am, const float* Bm, const float* W2, float* 
     else if (prec == LFT_PREC_BF16) k_selftest<bf16_t><<<1, 64, 0, st>>>(Am, Bm, W2, C, D);
     else return fail(LFT_ERR_ARG, "bad prec %d", prec);
     LFT_LAUNCH_OK("k_selftest");
+    return 0;
+}
+
+// ================================================================================ metrics
+int lft_view_metrics_scratch_bytes(int B, int A, int h, int w, size_t* out_bytes) {
+    if (!out_bytes || B < 1 || A < 1 || h < 1 || w < 1) return fail(LFT_ERR_ARG, "bad argument");
+    const size_t ntiles = (size_t)((h + kMetTile - 1) / kMetTile) * ((w + kMetTile - 1) / kMetTile);
+    *out_bytes = (size_t)B * A * A * ntiles * 3 * sizeof(double);
+    return 0;
+}
+int lft_view_metrics(const float* label, const float* out, int B, int A, int h, int w, float ssim_range, float* psnr, float* ssim,
+                     void* scratch, void* stream) {
+    if (!label || !out || !psnr || !ssim || !scratch || B < 1 || A < 1) return fail(LFT_ERR_ARG, "bad argument");
+    if (h < 11 || w < 11) return fail(LFT_ERR_SHAPE, "views of %dx%d are smaller than the 11x11 SSIM window", h, w);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ntiles = ((h + kMetTile - 1) / kMetTile) * ((w + kMetTile - 1) / kMetTile), nviews = B * A * A;
+    const double C1 = (0.01 * ssim_range) * (0.01 * ssim_range), C2 = (0.03 * ssim_range) * (0.03 * ssim_range);
+    k_view_metrics<<<dim3((unsigned)ntiles, (unsigned)nviews), 256, 0, st>>>(label, out, static_cast<double*>(scratch), A, h, w, C1, C2);
+    LFT_LAUNCH_OK("k_view_metrics");
+    k_view_metrics_final<<<blocks_for(nviews, 64), 64, 0, st>>>(static_cast<const double*>(scratch), nviews, ntiles, h, w, psnr, ssim);
+    LFT_LAUNCH_OK("k_view_metrics_final");
     return 0;
 }
 
