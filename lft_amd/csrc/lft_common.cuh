@@ -47,6 +47,15 @@ LFT_DEV void lft_stamp(int slot) {
 #define LFT_STAMP(slot) ((void)0)
 #endif
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one private 4 MiB L2): consecutive block
+// ids -- i.e. neighbouring tiles, which share halo rows -- land on eight different L2s and each fetches the shared rows
+// from HBM itself.  This bijective remap gives every XCD a CONTIGUOUS range of tiles instead, so a halo row is fetched
+// into one L2 once.  Pure performance: placement is not part of any correctness argument.
+LFT_DEV int xcd_tile(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 constexpr int LFT_C = 64;            // feature channels (reference option.py --channels, LFT.py:11)
 constexpr int LFT_E = 128;           // spatial token width 2C (reference LFT.py:124)
 constexpr float LFT_LN_EPS = 1e-5f;  // nn.LayerNorm default

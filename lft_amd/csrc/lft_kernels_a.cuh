@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void k_conv64(const T* __restrict__ in, T* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5, wave = threadIdx.x >> 6;
     const int hw = h * w, tpi = (hw + 127) >> 7;
-    const int im = blockIdx.x / tpi, p0 = (blockIdx.x % tpi) * 128;
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);                  // neighbouring tiles (shared halo rows) on one XCD
+    const int im = bid / tpi, p0 = (bid % tpi) * 128;
     const int tl = wave * 32 + r, p = p0 + tl;
     const bool ok = p < hw;
     const int t0 = p0 + wave * 32, nvalid = max(0, min(32, hw - t0));                 // this wave's 32 consecutive tokens

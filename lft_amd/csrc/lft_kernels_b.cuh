@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5, wave = threadIdx.x >> 6;
     const int hw = h * w, tpi = (hw + 127) >> 7;
-    const int im = blockIdx.x / tpi, p0 = (blockIdx.x % tpi) * 128;
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);                  // neighbouring tiles (shared halo rows) on one XCD
+    const int im = bid / tpi, p0 = (bid % tpi) * 128;
     const int tl = wave * 32 + r, p = p0 + tl;
     const bool ok = p < hw;
     const int pc = min(p, hw - 1);
@@ -429,7 +430,8 @@ __global__ __launch_bounds__(256, 2) void k_spa_attn_mfma(const bf16_t* __restri
     char* ldsK = smem;
     char* ldsV = smem + kAmSlots * kAmRow;
     const int tiles_x = (w + kAttTX - 1) / kAttTX, tiles_y = (h + kAttTY - 1) / kAttTY;
-    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, im = blockIdx.x / (tiles_x * tiles_y);
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);                  // vertically adjacent tiles share 4 of their 8 halo rows
+    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, im = bid / (tiles_x * tiles_y);
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int y0 = ty * kAttTY, x0 = tx * kAttTX, bxl = 8 * wave;          // block origin: (y0, x0 + bxl)
