@@ -33,6 +33,11 @@ extern "C" {
 #define LFT_PREC_F32 0
 #define LFT_PREC_BF16 1
 #define LFT_NUM_PARAMS 78
+/* GEMM arithmetic of the training step: exact fp32 MFMA, or fp32 operands split into bf16 hi + lo with three bf16
+ * MFMAs per product (~2^-16 relative per product, 5x the matrix-pipe rate).  Forward and backward of one step must
+ * use the same mode (the packed weights in the tape are in the mode's format). */
+#define LFT_MATH_F32 0
+#define LFT_MATH_BF16X3 1
 
 #define LFT_ERR_ARG (-1)         /* null pointer / bad enum */
 #define LFT_ERR_SHAPE (-2)       /* shape outside what this build supports */
@@ -105,9 +110,9 @@ int lft_train_tape_bytes(int B, int A, int h, int w, int s, size_t* out_bytes);
 int lft_train_grad_floats(int s, size_t* out_floats);
 int lft_train_tape_offset(const char* name, int B, int A, int h, int w, int s, size_t* out_float_offset);
 int lft_train_forward(const float* const* params, int nparams, const float* lr, float* out, void* tape,
-                      int B, int A, int h, int w, int s, void* stream);
+                      int B, int A, int h, int w, int s, int math, void* stream);
 int lft_train_backward(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
-                       int B, int A, int h, int w, int s, void* stream);
+                       int B, int A, int h, int w, int s, int math, void* stream);
 /* get_loss (reference LFT.py:269-277, torch.nn.L1Loss): *loss = mean |sr - hr|; if dsr != NULL also
  * dsr = gscale * sign(sr - hr) (gscale = 1/n for d loss / d sr).  scratch1024: 1024 floats of device scratch. */
 int lft_l1_loss(const float* sr, const float* hr, long long n, float* dsr, float gscale, float* loss, float* scratch1024, void* stream);

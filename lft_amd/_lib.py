@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("LFT_LIB_PATH") or os.path.join(HERE, "liblft_hip.so")
 SOURCES = ["lft_api.hip", "lft_common.cuh", "lft_kernels_a.cuh", "lft_kernels_b.cuh", "lft_train.cuh", "lft_train_host.cuh", "lft_metrics.cuh"]
 
 PREC_F32, PREC_BF16 = 0, 1
+MATH_F32, MATH_BF16X3 = 0, 1
 NUM_PARAMS = 78
 
 _lib = None
@@ -68,8 +69,8 @@ _SIGS = {
     "lft_train_tape_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "lft_train_grad_floats": (c_int, [c_int, POINTER(c_size_t)]),
     "lft_train_tape_offset": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
-    "lft_train_forward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "lft_train_backward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_train_forward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_train_backward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lft_l1_loss": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "lft_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
     "lft_view_metrics_scratch_bytes": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),

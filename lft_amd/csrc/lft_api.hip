@@ -186,7 +186,8 @@ template <typename T, bool PE_ONLY>
 int launch_spa1(unsigned nwg, const T* in, const T* ws, const float* ln, const T* petok, T* tok, T* q, T* k, T* v, T* pe_out,
                 int nimg, const Dims& d, hipStream_t st) {
     const size_t l16 = lds_spa1<T, 16>(d.w), l8 = lds_spa1<T, 8>(d.w);
-    const bool use8 = (l16 > 80 * 1024 && l8 <= 80 * 1024) || l16 > kMaxLds;
+    const size_t share = kMaxLds / LFT_SPA_OCC;                           // LDS per workgroup if LFT_SPA_OCC of them share a CU
+    const bool use8 = (l16 > share && l8 <= share) || l16 > kMaxLds;
     int rc;
     if (use8) {
         if ((rc = allow_lds(k_spa1<T, PE_ONLY, 8>, l8, "k_spa1"))) return rc;
@@ -663,22 +664,24 @@ int lft_train_tape_offset(const char* name, int B, int A, int h, int w, int s, s
     return 0;
 }
 int lft_train_forward(const float* const* params, int nparams, const float* lr, float* out, void* tape,
-                      int B, int A, int h, int w, int s, void* stream) {
+                      int B, int A, int h, int w, int s, int math, void* stream) {
     Dims d; int rc;
     if (!params || !lr || !out || !tape) return fail(LFT_ERR_ARG, "null pointer");
     if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
     for (int i = 0; i < nparams; ++i) if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
-    return train_forward(params, lr, out, static_cast<float*>(tape), d, static_cast<hipStream_t>(stream));
+    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32 or LFT_MATH_BF16X3, got %d", math);
+    return train_forward(params, lr, out, static_cast<float*>(tape), d, math, static_cast<hipStream_t>(stream));
 }
 int lft_train_backward(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
-                       int B, int A, int h, int w, int s, void* stream) {
+                       int B, int A, int h, int w, int s, int math, void* stream) {
     Dims d; int rc;
     if (!params || !lr || !tape || !dout || !grads) return fail(LFT_ERR_ARG, "null pointer");
     if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
     for (int i = 0; i < nparams; ++i) if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
-    return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, static_cast<hipStream_t>(stream));
+    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32 or LFT_MATH_BF16X3, got %d", math);
+    return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, math, static_cast<hipStream_t>(stream));
 }
 int lft_l1_loss(const float* sr, const float* hr, long long n, float* dsr, float gscale, float* loss, float* scratch1024, void* stream) {
     if (!sr || !hr || !loss || !scratch1024 || n < 1) return fail(LFT_ERR_ARG, "bad argument");

@@ -16,9 +16,15 @@
 #define LFT_UP_CHUNK 8
 #endif
 constexpr int kUpChunk = LFT_UP_CHUNK;    // k_up uses few registers: a smaller ring lets more workgroups share a CU
-constexpr int kSpaChunk = 16;   // fragments per ring chunk: one conv tap (4 k-steps x 4 row tiles), half an in_proj matrix
+#ifndef LFT_SPA_CHUNK
+#define LFT_SPA_CHUNK 16
+#endif
+#ifndef LFT_SPA_OCC
+#define LFT_SPA_OCC 2
+#endif
+constexpr int kSpaChunk = LFT_SPA_CHUNK;   // fragments per ring chunk: one conv tap (4 k-steps x 4 row tiles), half an in_proj matrix
 template <typename T, bool PE_ONLY, int CH = kSpaChunk>
-__global__ __launch_bounds__(256, 2) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
+__global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const T* __restrict__ petok,
                                               T* __restrict__ TOK, T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vv,
                                               T* __restrict__ pe_out, int nimg, int h, int w) {
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_attn_mfma(const bf16_t* __restri
 // Stream: Wo[4x8, natural k] {W1c[2x8] W2c[4x4]} x4  Wl[2x8]  (176 fragments).
 // ------------------------------------------------------------------------------------------
 template <typename T, bool SKIP>
-__global__ __launch_bounds__(256, 2) void k_spa2(const T* __restrict__ TOK, const T* __restrict__ O, const T* __restrict__ ws,
+__global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa2(const T* __restrict__ TOK, const T* __restrict__ O, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const T* __restrict__ skip, T* __restrict__ Y,
                                               long long ntok) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

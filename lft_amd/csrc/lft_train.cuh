@@ -14,6 +14,57 @@
 #include "lft_common.cuh"
 
 // ------------------------------------------------------------------------------------------
+// Split-bf16 products ("bf16x3").  The fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) is 16x slower than the
+// bf16 one, so an fp32 operand x is split into two bf16 numbers x = hi + lo (+ O(2^-17 x)) and a product is
+//   a * b ~= ah*bh + ah*bl + al*bh            (3 MFMAs, fp32 accumulate; the dropped al*bl is O(2^-18 a b))
+// i.e. fp32 operands with ~2^-16 relative error per product at 3/16 of the fp32-MFMA cost.
+// Packed weights in this mode: fragment f = [1 KiB hi piece][1 KiB lo piece] (same 2 KiB as an fp32 fragment).
+// ------------------------------------------------------------------------------------------
+struct Frag2 { Frag<bf16_t> hi, lo; };
+LFT_DEV Frag2 split_frag(const Frag<float>& f) {
+    Frag2 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = j < 4 ? f.lo[j] : f.hi[j - 4];
+        const bf16_t h = (bf16_t)x;
+        r.hi.v[j] = h;
+        r.lo.v[j] = (bf16_t)(x - (float)h);
+    }
+    return r;
+}
+LFT_DEV void mma3(const Frag2& a, const Frag2& b, f32x16& c) {
+    mma(a.lo, b.hi, c);
+    mma(a.hi, b.lo, c);
+    mma(a.hi, b.hi, c);
+}
+LFT_DEV Frag2 load_wfrag2(const float* __restrict__ stream, int f, int lane) {
+    const char* base = reinterpret_cast<const char*>(stream) + (size_t)f * 2048 + lane * 16;
+    Frag2 r;
+    r.hi.v = __builtin_bit_cast(bf16x8, load_raw16(base));
+    r.lo.v = __builtin_bit_cast(bf16x8, load_raw16(base + 1024));
+    return r;
+}
+// k_pack's twin for the split mode: same PackOp description (kind 0, natural k order), writes hi / lo pieces.
+__global__ __launch_bounds__(64) void k_pack_split(PackArgs args, float* __restrict__ dst) {
+    const int f = blockIdx.x, lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    int oi = 0;
+    for (int i = 0; i < args.nops; ++i)
+        if (f >= args.op[i].frag0) oi = i;
+    const PackOp& op = args.op[oi];
+    const int lf = f - op.frag0, nt = lf / op.ksteps, ks = lf % op.ksteps;
+    const int n = 32 * nt + r;
+    bf16_t* d = reinterpret_cast<bf16_t*>(dst) + (size_t)f * 1024;                 // 2 KiB = 1024 bf16 per fragment
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kk = op.k0 + 16 * ks + 8 * h + j;
+        const float v = n < op.nrows ? op.scale * op.src[(size_t)(op.row0 + n) * op.ld + kk * op.kmul + op.kadd] : 0.0f;
+        const bf16_t hi = (bf16_t)v;
+        d[lane * 8 + j] = hi;
+        d[512 + lane * 8 + j] = (bf16_t)(v - (float)hi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic linear / per-view 3x3 convolution on MFMA.
 //   Y[t][o] = act( sum_tap sum_i W(o, i, tap) * X[shift_tap(t)][i] ) (+ R[t][o])
 // taps == 1: plain Linear.  taps == 9: tap -> (dy, dx) = (tap/3 - 1, tap%3 - 1), the source token is
@@ -31,7 +82,7 @@ struct LinP {
     long long N;
 };
 
-template <int NT>
+template <int NT, bool M3>
 __global__ __launch_bounds__(256) void k_lin(const LinP p) {
     __shared__ __attribute__((aligned(16))) char scr_all[4 * TileIO<NT, float>::BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, kh = lane >> 5;
@@ -54,8 +105,14 @@ __global__ __launch_bounds__(256) void k_lin(const LinP p) {
         const int fbase = (tap * p.OT + ot0) * p.KS;
         for (int ks = 0; ks < p.KS; ++ks) {
             const Frag<float> b = load_row8(row + 16 * ks, ok, 0.0f);
+            if constexpr (M3) {
+                const Frag2 b2 = split_frag(b);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) mma(load_wfrag(p.Wp, fbase + nt * p.KS + ks, lane), b, acc[nt]);
+                for (int nt = 0; nt < NT; ++nt) mma3(load_wfrag2(p.Wp, fbase + nt * p.KS + ks, lane), b2, acc[nt]);
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mma(load_wfrag(p.Wp, fbase + nt * p.KS + ks, lane), b, acc[nt]);
+            }
         }
     }
     if (p.act) {
@@ -88,7 +145,7 @@ struct WgP {
     int igroups;
 };
 
-template <int NI>
+template <int NI, bool M3>
 __global__ __launch_bounds__(64) void k_wgrad(const WgP p) {
     const int lane = threadIdx.x, r = lane & 31, kh = lane >> 5;
     const int ot = blockIdx.y / p.igroups, ig = blockIdx.y % p.igroups, tap = blockIdx.z;
@@ -117,8 +174,14 @@ __global__ __launch_bounds__(64) void k_wgrad(const WgP p) {
                 if (j < 4) b[ni].lo[j] = ok ? bv : 0.0f; else b[ni].hi[j - 4] = ok ? bv : 0.0f;
             }
         }
+        if constexpr (M3) {
+            const Frag2 a2 = split_frag(a);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) mma(a, b[ni], acc[ni]);
+            for (int ni = 0; ni < NI; ++ni) mma3(a2, split_frag(b[ni]), acc[ni]);
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) mma(a, b[ni], acc[ni]);
+        }
     }
     float* dst = p.part + (long long)blockIdx.x * p.wsize + (size_t)tap * p.st;
 #pragma unroll

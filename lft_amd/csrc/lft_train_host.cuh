@@ -126,6 +126,26 @@ TrainLayout train_layout(const Dims& d) {
     return T;
 }
 
+int run_pack_split(std::vector<PackOp>& ops, float* dst, int expect_frags, hipStream_t st) {
+    int total = 0;
+    size_t i = 0;
+    while (i < ops.size()) {
+        PackArgs a{};
+        int nf = 0;
+        while (i < ops.size() && a.nops < LFT_PACK_MAXOPS) {
+            a.op[a.nops] = ops[i];
+            a.op[a.nops].frag0 = nf;
+            nf += ops[i].ntiles * ops[i].ksteps;
+            ++a.nops; ++i;
+        }
+        k_pack_split<<<nf, 64, 0, st>>>(a, dst + (size_t)total * 512);
+        LFT_LAUNCH_OK("k_pack_split");
+        total += nf;
+    }
+    if (total != expect_frags) return fail(LFT_ERR_ARG, "internal: stream has %d fragments, expected %d", total, expect_frags);
+    return 0;
+}
+
 // ---- launch helpers ----
 struct TrainCtx {
     const Dims& d;
@@ -133,6 +153,7 @@ struct TrainCtx {
     const TrainLayout& T;
     const WViews& W;
     hipStream_t st;
+    int math;                  // LFT_MATH_F32 or LFT_MATH_BF16X3
     float* F(size_t off) const { return tp + off; }
 };
 
@@ -144,8 +165,13 @@ int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int l
     if (nOT % 2 || (v.taps != 1 && (ot0 || nOT != v.OT))) return fail(LFT_ERR_ARG, "run_lin: bad tile block (view %d)", view);
     LinP p{X, ldx, c.F(c.T.wp) + (v.frag0 + (size_t)ot0 * v.KS) * 512, v.OT, v.KS, R, ldr, Y, ldy, v.taps, flip, act, c.d.h, c.d.w, N};
     const unsigned gx = (unsigned)((N + 127) / 128);
-    if (nOT % 4 == 0) k_lin<4><<<dim3(gx, (unsigned)(nOT / 4)), 256, 0, c.st>>>(p);
-    else k_lin<2><<<dim3(gx, (unsigned)(nOT / 2)), 256, 0, c.st>>>(p);
+    if (c.math == LFT_MATH_BF16X3) {
+        if (nOT % 4 == 0) k_lin<4, true><<<dim3(gx, (unsigned)(nOT / 4)), 256, 0, c.st>>>(p);
+        else k_lin<2, true><<<dim3(gx, (unsigned)(nOT / 2)), 256, 0, c.st>>>(p);
+    } else {
+        if (nOT % 4 == 0) k_lin<4, false><<<dim3(gx, (unsigned)(nOT / 4)), 256, 0, c.st>>>(p);
+        else k_lin<2, false><<<dim3(gx, (unsigned)(nOT / 2)), 256, 0, c.st>>>(p);
+    }
     LFT_LAUNCH_OK("k_lin");
     return 0;
 }
@@ -169,12 +195,15 @@ int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, in
     long long len = (N + nch - 1) / nch;
     len = (len + 15) & ~15LL;
     WgP p{dY, Co, X, Ci, c.F(c.T.part), wsize, Ci * taps, taps, 1, Co, Ci, taps, c.d.h, c.d.w, N, len, 1};
+    const bool m3 = c.math == LFT_MATH_BF16X3;
     if (Ci % 128 == 0) {
         p.igroups = Ci / 128;
-        k_wgrad<4><<<dim3((unsigned)nch, (unsigned)(Co / 32 * p.igroups), (unsigned)taps), 64, 0, c.st>>>(p);
+        const dim3 g((unsigned)nch, (unsigned)(Co / 32 * p.igroups), (unsigned)taps);
+        if (m3) k_wgrad<4, true><<<g, 64, 0, c.st>>>(p); else k_wgrad<4, false><<<g, 64, 0, c.st>>>(p);
     } else {
         p.igroups = Ci / 64;
-        k_wgrad<2><<<dim3((unsigned)nch, (unsigned)(Co / 32 * p.igroups), (unsigned)taps), 64, 0, c.st>>>(p);
+        const dim3 g((unsigned)nch, (unsigned)(Co / 32 * p.igroups), (unsigned)taps);
+        if (m3) k_wgrad<2, true><<<g, 64, 0, c.st>>>(p); else k_wgrad<2, false><<<g, 64, 0, c.st>>>(p);
     }
     LFT_LAUNCH_OK("k_wgrad");
     k_reduce<<<blocks_for(wsize, 64), 256, 0, c.st>>>(c.F(c.T.part), nch, wsize, wsize, dW, accumulate);
@@ -228,16 +257,17 @@ int ang_attn(const TrainCtx& c, const float* QK, const float* Vv, float* O, cons
 }
 
 // ---------------------------------------------------------------------------- forward with tape
-int train_forward(const float* const* P, const float* lr, float* out, float* tape, const Dims& d, hipStream_t st) {
+int train_forward(const float* const* P, const float* lr, float* out, float* tape, const Dims& d, int math, hipStream_t st) {
     const TrainLayout T = train_layout(d);
     std::vector<PackOp> ops;
     const WViews WV = build_views(P, d.s, &ops);
-    const TrainCtx c{d, tape, T, WV, st};
+    const TrainCtx c{d, tape, T, WV, st, math};
     const long long N = d.ntok;
     const int nimg = d.B * d.V;
     int rc;
 #define TRY(x) do { if ((rc = (x))) return rc; } while (0)
-    TRY(run_pack<float>(ops, c.F(T.wp), (int)WV.nfrags, st));       // both orientations of every matrix, for this step's weights
+    if (math == LFT_MATH_BF16X3) TRY(run_pack_split(ops, c.F(T.wp), (int)WV.nfrags, st));
+    else TRY(run_pack<float>(ops, c.F(T.wp), (int)WV.nfrags, st));   // both orientations of every matrix, for this step's weights
     k_pe_plain<<<blocks_for(std::max(d.V, d.hw) * 64, 256), 256, 0, st>>>(c.F(T.pe_ang), c.F(T.pe_spa), d.V, d.h, d.w);
     LFT_LAUNCH_OK("k_pe_plain");
     // conv_init0, conv_init + residual (LFT.py:65-66)
@@ -291,10 +321,10 @@ int train_forward(const float* const* P, const float* lr, float* out, float* tap
 }
 
 // ---------------------------------------------------------------------------- backward
-int train_backward(const float* const* P, const float* lr, float* tape, const float* dout, float* G, const Dims& d, hipStream_t st) {
+int train_backward(const float* const* P, const float* lr, float* tape, const float* dout, float* G, const Dims& d, int math, hipStream_t st) {
     const TrainLayout T = train_layout(d);
     const WViews WV = build_views(nullptr, d.s, nullptr);            // packed by this step's lft_train_forward
-    const TrainCtx c{d, tape, T, WV, st};
+    const TrainCtx c{d, tape, T, WV, st, math};
     const ParamInfo pi = param_info(d.s);
     const long long N = d.ntok;
     const int ss = d.s * d.s, nimg = d.B * d.V;

@@ -68,6 +68,8 @@ class get_model(nn.Module):
                 t.zero_()
             _attach(self, name, nn.Parameter(t))
             self._names.append(name)
+        # GEMM arithmetic of the training kernels: 'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16, ~1e-5 relative)
+        self.train_math = getattr(args, "lft_train_math", "fp32")
         self._packed = None        # (key, tensor)
         self._work = {}            # slot -> (key, tensor)
         self._side_streams = {}    # device -> [torch.cuda.Stream]
@@ -120,7 +122,7 @@ class get_model(nn.Module):
             # training (reference train.py:89-107): the fp32 forward-with-tape / backward kernels, whatever self.precision
             # says; gradients reach the 78 parameters, none flows to the input (the reference's data has none either)
             from .train import LFTFunction
-            return LFTFunction.apply(lr.contiguous().float(), A, s, *self._params_in_order())
+            return LFTFunction.apply(lr.contiguous().float(), A, s, self.train_math, *self._params_in_order())
         h, w = H // A, W // A
         x = lr.contiguous().float()
         prec = _PREC[self.precision]

@@ -54,8 +54,11 @@ def _ptr_array(ps):
     return (ctypes.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
 
 
-def train_forward(ps, lr, A, s, tape=None):
-    """lft_train_forward: returns (out, tape)."""
+MATH = {"fp32": _lib.MATH_F32, "bf16x3": _lib.MATH_BF16X3}
+
+
+def train_forward(ps, lr, A, s, tape=None, math="fp32"):
+    """lft_train_forward: returns (out, tape).  math: 'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 products)."""
     B, _, H, W = lr.shape
     h, w = H // A, W // A
     dev = lr.device
@@ -65,11 +68,11 @@ def train_forward(ps, lr, A, s, tape=None):
     out = torch.empty((B, 1, H * s, W * s), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     _lib.check(_lib.lib().lft_train_forward(_ptr_array(ps), len(ps), lr.data_ptr(), out.data_ptr(), tape.data_ptr(),
-                                            B, A, h, w, s, stream), "lft_train_forward")
+                                            B, A, h, w, s, MATH[math], stream), "lft_train_forward")
     return out, tape
 
 
-def train_backward(ps, lr, tape, dout, A, s, grads=None):
+def train_backward(ps, lr, tape, dout, A, s, grads=None, math="fp32"):
     """lft_train_backward: returns the flat gradient buffer (78 gradients back to back, state_dict order)."""
     B, _, H, W = lr.shape
     h, w = H // A, W // A
@@ -78,7 +81,7 @@ def train_backward(ps, lr, tape, dout, A, s, grads=None):
         grads = torch.empty(grad_floats(s), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     _lib.check(_lib.lib().lft_train_backward(_ptr_array(ps), len(ps), lr.data_ptr(), tape.data_ptr(), dout.data_ptr(), grads.data_ptr(),
-                                             B, A, h, w, s, stream), "lft_train_backward")
+                                             B, A, h, w, s, MATH[math], stream), "lft_train_backward")
     return grads
 
 
@@ -86,11 +89,11 @@ class LFTFunction(torch.autograd.Function):
     """autograd node of the whole network: forward saves the tape, backward returns the 78 parameter gradients."""
 
     @staticmethod
-    def forward(ctx, lr, A, s, *params):
+    def forward(ctx, lr, A, s, math, *params):
         ps = [p.detach() for p in params]
         with torch.cuda.device(lr.device):
-            out, tape = train_forward(ps, lr, A, s)
-        ctx.A, ctx.s, ctx.tape, ctx.lr = A, s, tape, lr
+            out, tape = train_forward(ps, lr, A, s, math=math)
+        ctx.A, ctx.s, ctx.tape, ctx.lr, ctx.math = A, s, tape, lr, math
         ctx.save_for_backward(*params)
         return out
 
@@ -98,13 +101,13 @@ class LFTFunction(torch.autograd.Function):
     def backward(ctx, dout):
         ps = [p.detach() for p in ctx.saved_tensors]
         with torch.cuda.device(dout.device):
-            flat = train_backward(ps, ctx.lr, ctx.tape, dout.contiguous().float(), ctx.A, ctx.s)
+            flat = train_backward(ps, ctx.lr, ctx.tape, dout.contiguous().float(), ctx.A, ctx.s, math=ctx.math)
         ctx.tape = None
         grads, off = [], 0
         for p in ps:
             grads.append(flat[off:off + p.numel()].view(p.shape))
             off += p.numel()
-        return (None, None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
 class TrainStep:
@@ -116,8 +119,9 @@ class TrainStep:
     buffer and averaged inside the Adam kernel (L1Loss is a mean over the local shard, shards are equal: SURVEY 8e).
     """
 
-    def __init__(self, net, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, process_group=None):
+    def __init__(self, net, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, math: Optional[str] = None):
         self.net, self.lr, self.betas, self.eps = net, float(lr), betas, float(eps)
+        self.math = math or getattr(net, "train_math", "fp32")
         self.group = process_group
         ps = net._params_in_order()
         dev = ps[0].device
@@ -153,13 +157,13 @@ class TrainStep:
             nb = tape_bytes(B, self.A, h, w, self.s)
             if self._tape is None or self._tape.numel() != nb:
                 self._tape = torch.empty(nb, dtype=torch.uint8, device=dev)
-            out, _ = train_forward(self.params, lr_in, self.A, self.s, tape=self._tape)
+            out, _ = train_forward(self.params, lr_in, self.A, self.s, tape=self._tape, math=self.math)
             dout = torch.empty_like(out)
             n = out.numel()
             loss = self._scratch[1024:1025]
             _lib.check(L.lft_l1_loss(out.data_ptr(), hr.data_ptr(), n, dout.data_ptr(), 1.0 / n, loss.data_ptr(),
                                      self._scratch.data_ptr(), stream), "lft_l1_loss")
-            train_backward(self.params, lr_in, self._tape, dout, self.A, self.s, grads=self.flat_grads)
+            train_backward(self.params, lr_in, self._tape, dout, self.A, self.s, grads=self.flat_grads, math=self.math)
             gscale = sum_gradients_(self.flat_grads, self.group)          # the step's only collective
             self.t += 1
             _lib.check(L.lft_adam_step(self.flat_params.data_ptr(), self.flat_grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),

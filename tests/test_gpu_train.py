@@ -45,9 +45,12 @@ def make_inputs(A, s, B, h, w):
     return sd_np, lr, hr
 
 
-@pytest.fixture(scope="module", params=CASES, ids=lambda c: "A%d_s%d_B%d_%dx%d" % c)
+MATHS = ["fp32", "bf16x3"]        # exact fp32 MFMA / split-bf16 products: same tolerance for both
+
+
+@pytest.fixture(scope="module", params=[(c, m) for c in CASES for m in MATHS], ids=lambda cm: "A%d_s%d_B%d_%dx%d" % cm[0] + "_" + cm[1])
 def case(request):
-    A, s, B, h, w = request.param
+    (A, s, B, h, w), math = request.param
     sd_np, lr, hr = make_inputs(A, s, B, h, w)
     sd = O.state_from_numpy(sd_np)
     taps = {}
@@ -56,15 +59,15 @@ def case(request):
     names = [n for n, _, _ in param_table(64, s)]
     ps = [torch.from_numpy(sd_np[n]).to(G.DEV).contiguous() for n in names]
     lr_d, hr_d = lr.to(G.DEV), hr.to(G.DEV)
-    out, tape = T.train_forward(ps, lr_d, A, s)
+    out, tape = T.train_forward(ps, lr_d, A, s, math=math)
     n = out.numel()
     dout = torch.empty_like(out)
     scratch = torch.empty(1025, device=G.DEV)
     _lib.check(_lib.lib().lft_l1_loss(out.data_ptr(), hr_d.data_ptr(), n, dout.data_ptr(), 1.0 / n, scratch[1024:].data_ptr(),
                                       scratch.data_ptr(), G.stream()), "lft_l1_loss")
-    flat = T.train_backward(ps, lr_d, tape, dout, A, s)
+    flat = T.train_backward(ps, lr_d, tape, dout, A, s, math=math)
     torch.cuda.synchronize()
-    return dict(sd=sd, A=A, s=s, B=B, h=h, w=w, names=names, ps=ps, lr=lr_d, hr=hr_d, out=out, tape=tape, flat=flat, loss=float(scratch[1024]),
+    return dict(math=math, sd=sd, A=A, s=s, B=B, h=h, w=w, names=names, ps=ps, lr=lr_d, hr=hr_d, out=out, tape=tape, flat=flat, loss=float(scratch[1024]),
                 taps=taps, out_ref=out_ref, loss_ref=float(loss_ref), grads_ref=grads_ref, dout=dout)
 
 
@@ -77,7 +80,7 @@ def test_forward_tape_matches_oracle(case):
         assert not torch.isnan(got).any(), name
         assert G.rel_max(got, ref) <= TOL, f"{name}: " + G.err_report(got.contiguous(), ref)
     got, ref = case["out"].cpu(), case["out_ref"]
-    print("train forward: " + G.err_report(got, ref))
+    print(f"train forward [{case['math']}]: " + G.err_report(got, ref))
     assert G.rel_max(got, ref) <= TOL
     assert abs(case["loss"] - case["loss_ref"]) <= 1e-5 * max(1.0, abs(case["loss_ref"]))
 
@@ -112,7 +115,7 @@ def compare_all(case, grads_ref, what):
             worst = (rel, name)
         assert err <= TOL * scale + 1e-10, f"{name}: " + G.err_report(got, ref)
     assert off == case["flat"].numel()
-    print(f"{what}: worst gradient rel err {worst[0]:.2e} ({worst[1]})")
+    print(f"{what} [{case['math']}]: worst gradient rel err {worst[0]:.2e} ({worst[1]})")
 
 
 def test_all_78_gradients_exact_given_our_branches(case):
@@ -127,17 +130,21 @@ def test_all_78_gradients_exact_given_our_branches(case):
 def test_all_78_gradients_match_oracle_autograd(case):
     if (case["A"], case["s"], case["B"], case["h"], case["w"]) in ON_A_KINK:
         pytest.skip("input sits on a ReLU kink (see the note at the top); covered exactly by the branch-given test")
+    if case["math"] == "bf16x3":
+        pytest.skip("2^-16 operand rounding puts ~30x more units within rounding of a kink than fp32 does: at these token "
+                    "counts some branch always differs from the oracle's; covered exactly by the branch-given test")
     compare_all(case, case["grads_ref"], "end to end vs oracle autograd")
 
 
 def test_backward_is_deterministic(case):
-    again = T.train_backward(case["ps"], case["lr"], case["tape"], case["dout"], case["A"], case["s"])
+    again = T.train_backward(case["ps"], case["lr"], case["tape"], case["dout"], case["A"], case["s"], math=case["math"])
     torch.cuda.synchronize()
     assert torch.equal(again, case["flat"])
 
 
+@pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("name", ["train_a3_s2_b2_6x6", "train_a2_s4_b1_8x5"])
-def test_train_step_matches_reference_fixture(name, golden_dir):
+def test_train_step_matches_reference_fixture(name, math, golden_dir):
     """TrainStep (flat buffers, C-ABI loss / backward / Adam) against the reference network + torch.optim.Adam."""
     from model import LFT
     g = np.load(os.path.join(golden_dir, name + ".npz"))
@@ -148,7 +155,7 @@ def test_train_step_matches_reference_fixture(name, golden_dir):
     net = net.to(G.DEV).train()
     lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=iseed)).to(G.DEV)
     hr = torch.from_numpy(g["hr"]).to(G.DEV)
-    ts = T.TrainStep(net, lr=2e-4)
+    ts = T.TrainStep(net, lr=2e-4, math=math)
     losses = []
     for step in range(steps):
         losses.append(float(ts.step(lr, hr)))
@@ -157,12 +164,18 @@ def test_train_step_matches_reference_fixture(name, golden_dir):
                 got = p.grad.detach().cpu().numpy().ravel()
                 ref = g[f"grad_{k}_sub"]
                 scale = max(float(np.abs(ref).max()), 1e-12)
-                assert np.abs(got[sub_indices(got.size)] - ref).max() <= TOL * scale + 1e-10, k
-    assert np.allclose(losses, g["losses"], rtol=0, atol=1e-5), (losses, g["losses"])
+                sub = got[sub_indices(got.size)]
+                if math == "fp32":
+                    assert np.abs(sub - ref).max() <= TOL * scale + 1e-10, k
+                else:       # branch flips against the reference are certain here (see the skip note above): bound the rms instead
+                    assert np.sqrt(np.mean((sub - ref) ** 2)) <= 3e-2 * max(np.sqrt(np.mean(ref ** 2)), 1e-12), k
+    assert np.allclose(losses, g["losses"], rtol=0, atol=1e-5 if math == "fp32" else 1e-4), (losses, g["losses"])
     for k, p in net.state_dict().items():
         got = p.cpu().numpy().ravel()
         ref = g[f"post_{k}_sub"]
-        assert np.abs(got[sub_indices(got.size)] - ref).max() <= 1.05 * steps * 2e-4, k
+        # Adam moves a weight by about +-lr per step whatever the gradient's size, so where |g| is at rounding level the two
+        # implementations may step in opposite directions: bound the worst case by the step size, the mean tightly
+        assert np.abs(got[sub_indices(got.size)] - ref).max() <= (1.05 if math == "fp32" else 4.0) * steps * 2e-4, k
         assert np.mean(np.abs(got[sub_indices(got.size)] - ref)) <= 2e-5, k
     # the inference path sees the updated weights
     with torch.no_grad():

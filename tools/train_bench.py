@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--lr", type=int, default=32)
     ap.add_argument("--scale", type=int, default=2, choices=[2, 4])
     ap.add_argument("--phases", action="store_true")
+    ap.add_argument("--math", default="bf16x3", choices=["fp32", "bf16x3"])
     args = ap.parse_args()
     from lft_amd import dp, train as T
     from lft_amd.params import deterministic_state, synthetic_lr
@@ -44,7 +45,7 @@ def main():
     net = net.to(dev).train()
     lr = torch.from_numpy(synthetic_lr(args.batch, A, H, H, seed=rank)).to(dev)
     hr = torch.from_numpy(np.random.Generator(np.random.PCG64([2, rank])).random((args.batch, 1, A * H * S, A * H * S), dtype=np.float32)).to(dev)
-    ts = T.TrainStep(net, lr=2e-4)
+    ts = T.TrainStep(net, lr=2e-4, math=args.math)
 
     def sync():
         if dist is not None:
@@ -67,7 +68,7 @@ def main():
         flops_fwd = {2: 58.85e9, 4: 61.73e9}[S] * (H * H / 1024.0) * (V / 25.0)      # SURVEY 8d (approximate outside cfg shapes)
         out = {"metric": f"LF patches/sec training ({A}x{A} angRes, {H}x{H} LR, {S}xSR, fp32, Adam)", "value": args.batch * world * args.steps / dt,
                "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-               "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "dtype": "f32" if args.math == "fp32" else "f32 (split-bf16 products)", "data": "synthetic",
                "config": {"workload": f"LFT {A}x{A} angRes {S}xSR training step, batch={args.batch} per GPU, {H}x{H} LR patches",
                           "global_batch": args.batch * world, "parallelism": f"dp{world} (one flat-gradient all-reduce per step)"},
                "loss_first_last": [lv[0], lv[-1]],
