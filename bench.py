@@ -141,8 +141,8 @@ def note(msg: str) -> None:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=4, help="LF patches per GPU per step (BASELINE configs[1]: 4)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--ang", type=int, default=5, help="angular resolution (default: the BASELINE metric's 5)")
