@@ -119,9 +119,15 @@ class TrainStep:
     buffer and averaged inside the Adam kernel (L1Loss is a mean over the local shard, shards are equal: SURVEY 8e).
     """
 
-    def __init__(self, net, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, math: Optional[str] = None):
+    def __init__(self, net, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, math: Optional[str] = None,
+                 graph: bool = True):
         self.net, self.lr, self.betas, self.eps = net, float(lr), betas, float(eps)
         self.math = math or getattr(net, "train_math", "fp32")
+        # forward + loss + backward are ~450 kernel launches; for a fixed batch shape they are captured once into a HIP
+        # graph and replayed (the kernels read the weights through the same flat buffer every step, and re-pack them
+        # inside the graph).  The all-reduce and the Adam kernel (whose bias corrections change every step) stay eager.
+        self.use_graph = bool(graph)
+        self._graphs = {}
         self.group = process_group
         ps = net._params_in_order()
         dev = ps[0].device
@@ -146,6 +152,38 @@ class TrainStep:
         self._tape = None
         self._scratch = torch.empty(1024 + 1, dtype=torch.float32, device=dev)
 
+    def _fwd_loss_bwd(self, lr_in, hr, tape, dout, loss):
+        L = _lib.lib()
+        dev = lr_in.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        out, _ = train_forward(self.params, lr_in, self.A, self.s, tape=tape, math=self.math)
+        n = out.numel()
+        _lib.check(L.lft_l1_loss(out.data_ptr(), hr.data_ptr(), n, dout.data_ptr(), 1.0 / n, loss.data_ptr(),
+                                 self._scratch.data_ptr(), stream), "lft_l1_loss")
+        train_backward(self.params, lr_in, tape, dout, self.A, self.s, grads=self.flat_grads, math=self.math)
+        return out
+
+    def _graph_for(self, lr_in, hr):
+        key = (tuple(lr_in.shape), str(lr_in.device))
+        g = self._graphs.get(key)
+        if g is None:
+            dev = lr_in.device
+            B, _, H, W = lr_in.shape
+            h, w = H // self.A, W // self.A
+            g = {"lr": lr_in.clone(), "hr": hr.clone(), "dout": torch.empty_like(hr),
+                 "tape": torch.empty(tape_bytes(B, self.A, h, w, self.s), dtype=torch.uint8, device=dev)}
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                      # eager warm-up: sets kernel attributes, sizes nothing lazily later
+                self._fwd_loss_bwd(g["lr"], g["hr"], g["tape"], g["dout"], self._scratch[1024:1025])
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["graph"]):
+                g["out"] = self._fwd_loss_bwd(g["lr"], g["hr"], g["tape"], g["dout"], self._scratch[1024:1025])
+            self._graphs[key] = g
+        return g
+
     def step(self, lr_in: torch.Tensor, hr: torch.Tensor) -> torch.Tensor:
         from .dp import sum_gradients_
         dev = lr_in.device
@@ -153,17 +191,18 @@ class TrainStep:
         h, w = H // self.A, W // self.A
         L = _lib.lib()
         with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            nb = tape_bytes(B, self.A, h, w, self.s)
-            if self._tape is None or self._tape.numel() != nb:
-                self._tape = torch.empty(nb, dtype=torch.uint8, device=dev)
-            out, _ = train_forward(self.params, lr_in, self.A, self.s, tape=self._tape, math=self.math)
-            dout = torch.empty_like(out)
-            n = out.numel()
             loss = self._scratch[1024:1025]
-            _lib.check(L.lft_l1_loss(out.data_ptr(), hr.data_ptr(), n, dout.data_ptr(), 1.0 / n, loss.data_ptr(),
-                                     self._scratch.data_ptr(), stream), "lft_l1_loss")
-            train_backward(self.params, lr_in, self._tape, dout, self.A, self.s, grads=self.flat_grads, math=self.math)
+            if self.use_graph:
+                g = self._graph_for(lr_in.contiguous().float(), hr.contiguous().float())
+                g["lr"].copy_(lr_in)
+                g["hr"].copy_(hr)
+                g["graph"].replay()
+            else:
+                nb = tape_bytes(B, self.A, h, w, self.s)
+                if self._tape is None or self._tape.numel() != nb:
+                    self._tape = torch.empty(nb, dtype=torch.uint8, device=dev)
+                self._fwd_loss_bwd(lr_in.contiguous().float(), hr.contiguous().float(), self._tape, torch.empty_like(hr), loss)
+            stream = torch.cuda.current_stream(dev).cuda_stream
             gscale = sum_gradients_(self.flat_grads, self.group)          # the step's only collective
             self.t += 1
             _lib.check(L.lft_adam_step(self.flat_params.data_ptr(), self.flat_grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--scale", type=int, default=2, choices=[2, 4])
     ap.add_argument("--phases", action="store_true")
     ap.add_argument("--math", default="bf16x3", choices=["fp32", "bf16x3"])
+    ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
     from lft_amd import dp, train as T
     from lft_amd.params import deterministic_state, synthetic_lr
@@ -45,7 +46,7 @@ def main():
     net = net.to(dev).train()
     lr = torch.from_numpy(synthetic_lr(args.batch, A, H, H, seed=rank)).to(dev)
     hr = torch.from_numpy(np.random.Generator(np.random.PCG64([2, rank])).random((args.batch, 1, A * H * S, A * H * S), dtype=np.float32)).to(dev)
-    ts = T.TrainStep(net, lr=2e-4, math=args.math)
+    ts = T.TrainStep(net, lr=2e-4, math=args.math, graph=not args.no_graph)
 
     def sync():
         if dist is not None:
