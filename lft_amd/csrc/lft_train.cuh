@@ -475,7 +475,7 @@ __global__ __launch_bounds__(8 * VP) void k_ang_attn(const float* __restrict__ Q
 // ------------------------------------------------------------------------------------------
 // Spatial windowed attention (reference LFT.py:147-162,183-187): 8 heads x 16, clamped 5x5 window with the
 // reference's min(h, x+3) column bound; a query with an empty window (h < w) outputs 0 and passes no gradient.
-// Q, K, Vv, O: [N][128].  Thread = (token, head).
+// Q, K, Vv, O: [N][128].
 //   MODE 0: forward.   MODE 1: backward pass A (dQ and per-(token, head) stats m, 1/l, D).
 //   MODE 2: backward pass B, gather form: key j collects from the <= 25 queries i = j - (dy, dx) that see it.
 // ------------------------------------------------------------------------------------------
@@ -497,52 +497,105 @@ LFT_DEV void st16(float* p, const float (&o)[16]) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) store4(p + 4 * g, f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]});
 }
+// ------------------------------------------------------------------------------------------
+// The three window-attention passes, LDS-tiled.
+// A workgroup owns an 8 x 16 tile of queries of one view image and one PAIR of heads (32 channels); the (8+4) x (16+4)
+// halo tile of the two tensors a pass gathers from (K,V for MODE 0/1; Q,dO (+ per-row stats) for MODE 2) is staged in
+// LDS once -- every row is used by up to 25 queries x 2 heads -- with rows padded to 144 B so that the 16-byte reads of
+// 8 neighbouring lanes fall on distinct banks.  Thread = (query, head of the pair).  Tokens outside the image are
+// zero-filled; taps outside the window get weight 0 (MODE 0/1: -inf score; MODE 2: 1/l = 0 in the zero-filled stats).
+// ------------------------------------------------------------------------------------------
+constexpr int kWaTY = 8, kWaTX = 16, kWaHR = kWaTY + 4, kWaHC = kWaTX + 4, kWaSlots = kWaHR * kWaHC, kWaRow = 36;   // floats per staged row
+constexpr int kWaTile = kWaSlots * kWaRow;                     // floats per staged tensor
+constexpr size_t kWaLds = (size_t)(2 * kWaTile + kWaSlots * 6) * sizeof(float);
+
+LFT_DEV void wa_stage(const float* __restrict__ src, float* lds, long long img0, int y0, int x0, int hp, int h, int w) {
+    for (int idx = threadIdx.x; idx < kWaSlots * 8; idx += 256) {
+        const int slot = idx >> 3, piece = idx & 7;
+        const int gy = y0 - 2 + slot / kWaHC, gx = x0 - 2 + slot % kWaHC;
+        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+        const f32x4 v = load4(src + (size_t)(in ? img0 + gy * w + gx : img0) * 128 + hp * 32 + piece * 4);
+        *reinterpret_cast<f32x4*>(lds + slot * kWaRow + piece * 4) = in ? v : f32x4{0, 0, 0, 0};
+    }
+}
+LFT_DEV void lds16(const float* p, float (&o)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[4 * g + j] = v[j];
+    }
+}
 template <int MODE>
-__global__ __launch_bounds__(256) void k_win_attn(const float* __restrict__ Q, const float* __restrict__ K,
-                                                  const float* __restrict__ Vv, float* __restrict__ O,
-                                                  const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ dK,
-                                                  float* __restrict__ dV, float* __restrict__ stats, long long ntok, int h, int w) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long tok = idx >> 3;
-    const int head = (int)(idx & 7);
-    if (tok >= ntok) return;
-    const int hw = h * w;
-    const int pix = (int)(tok % hw);
-    const long long img0 = tok - pix;
-    const int y = pix / w, x = pix % w;
-    const float scale = 0.25f, scale2 = 0.25f * LFT_LOG2E;           // 1 / sqrt(16); softmax evaluated as 2^(s log2 e - m)
-    const size_t off = (size_t)tok * 128 + head * 16;
+__global__ __launch_bounds__(256, 2) void k_win_attn_lds(const float* __restrict__ Q, const float* __restrict__ K,
+                                                         const float* __restrict__ Vv, float* __restrict__ O,
+                                                         const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ dK,
+                                                         float* __restrict__ dV, float* __restrict__ stats, int h, int w) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float* tA = wsm;                        // K (MODE 0/1) or Q (MODE 2)
+    float* tB = wsm + kWaTile;              // V (MODE 0/1) or dO (MODE 2)
+    float* tS = wsm + 2 * kWaTile;          // MODE 2: stats of the halo queries, [slot][2 heads][3]
+    const int tiles_x = (w + kWaTX - 1) / kWaTX, tiles_y = (h + kWaTY - 1) / kWaTY;
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, im = bid / (tiles_x * tiles_y);
+    const int hp = blockIdx.y;
+    const int y0 = ty * kWaTY, x0 = tx * kWaTX;
+    const long long img0 = (long long)im * h * w;
+    const int hl = threadIdx.x >> 7, qi = threadIdx.x & 127, qy = qi >> 4, qx = qi & 15;
+    const int y = y0 + qy, x = x0 + qx;
+    const bool valid = y < h && x < w;
+    const long long tok = img0 + min(y, h - 1) * w + min(x, w - 1);
+    const size_t off = (size_t)tok * 128 + hp * 32 + hl * 16;
+    const float scale = 0.25f, scale2 = 0.25f * LFT_LOG2E;
+    wa_stage(MODE == 2 ? Q : K, tA, img0, y0, x0, hp, h, w);
+    wa_stage(MODE == 2 ? dO : Vv, tB, img0, y0, x0, hp, h, w);
+    if (MODE == 2) {
+        for (int idx = threadIdx.x; idx < kWaSlots * 6; idx += 256) {
+            const int slot = idx / 6, e = idx % 6;
+            const int gy = y0 - 2 + slot / kWaHC, gx = x0 - 2 + slot % kWaHC;
+            const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+            tS[idx] = in ? stats[((size_t)(img0 + gy * w + gx) * 8 + hp * 2) * 3 + e] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const float* bA = tA + (qy * kWaHC + qx) * kWaRow + hl * 16;          // tap (ty, tx) adds (ty * kWaHC + tx) * kWaRow
+    const float* bB = tB + (qy * kWaHC + qx) * kWaRow + hl * 16;
     if (MODE == 0 || MODE == 1) {
-        const int y0 = max(0, y - 2), y1 = min(h, y + 3), x0 = max(0, x - 2), x1 = min(min(h, x + 3), w);   // LFT.py:150-160 (sic)
-        float q[16], kv[16], vv[16], dov[16];
+        const int wy0 = max(0, y - 2), wy1 = min(h, y + 3), wx0 = max(0, x - 2), wx1 = min(min(h, x + 3), w);   // LFT.py:150-160 (sic)
+        float q[16], kv[16], vv[16], dov[16], sc[25];
         ld16(Q + off, q);
         if (MODE == 1) ld16(dO + off, dov);
-        // one pass, running maximum (K and V of a key are read once): all accumulators are linear in the weights
-        float m = -INFINITY, l = 0.0f, D = 0.0f, o[16], a2[16];
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+            const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
+            const bool ok = ky >= wy0 && ky < wy1 && kx >= wx0 && kx < wx1;
+            lds16(bA + ((t / 5) * kWaHC + t % 5) * kWaRow, kv);
+            sc[t] = ok ? scale2 * dot16(q, kv) : -INFINITY;
+            m = fmaxf(m, sc[t]);
+        }
+        if (m == -INFINITY) m = 0.0f;                                      // empty window (h < w): all weights 0
+        float l = 0.0f, D = 0.0f, o[16], a2[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) { o[c] = 0.0f; a2[c] = 0.0f; }
-        for (int ky = y0; ky < y1; ++ky)
-#pragma unroll 1
-            for (int kx = x0; kx < x1; ++kx) {
-                const size_t ko = (size_t)(img0 + ky * w + kx) * 128 + head * 16;
-                ld16(K + ko, kv);
-                ld16(Vv + ko, vv);
-                const float sj = scale2 * dot16(q, kv);
-                const float mn = fmaxf(m, sj);
-                const float corr = fast_exp2(m - mn), pj = fast_exp2(sj - mn);     // first key: 2^(-inf) = 0
-                m = mn;
-                l = l * corr + pj;
-                if (MODE == 0) {
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) o[c] = o[c] * corr + pj * vv[c];
-                } else {
-                    const float dp = dot16(dov, vv);
-                    D = D * corr + pj * dp;
+        for (int t = 0; t < 25; ++t) {
+            const float pj = fast_exp2(sc[t] - m);
+            l += pj;
+            lds16(bB + ((t / 5) * kWaHC + t % 5) * kWaRow, vv);
+            if (MODE == 0) {
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) { o[c] = o[c] * corr + pj * dp * kv[c]; a2[c] = a2[c] * corr + pj * kv[c]; }
-                }
+                for (int c = 0; c < 16; ++c) o[c] += pj * vv[c];
+            } else {
+                lds16(bA + ((t / 5) * kWaHC + t % 5) * kWaRow, kv);
+                const float dp = dot16(dov, vv);
+                D += pj * dp;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) { o[c] += pj * dp * kv[c]; a2[c] += pj * kv[c]; }
             }
-        const float inv = l > 0.0f ? 1.0f / l : 0.0f;                  // empty window (h < w): output 0, no gradient
+        }
+        if (!valid) return;
+        const float inv = l > 0.0f ? 1.0f / l : 0.0f;
         if (MODE == 0) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) o[c] *= inv;
@@ -552,32 +605,30 @@ __global__ __launch_bounds__(256) void k_win_attn(const float* __restrict__ Q, c
 #pragma unroll
             for (int c = 0; c < 16; ++c) o[c] = scale * inv * (o[c] - D * a2[c]);
             st16(dQ + off, o);
-            float* s3 = stats + ((size_t)tok * 8 + head) * 3;
-            s3[0] = l > 0.0f ? m : 0.0f; s3[1] = inv; s3[2] = D;        // m in the log2 domain
+            float* s3 = stats + ((size_t)tok * 8 + hp * 2 + hl) * 3;
+            s3[0] = m; s3[1] = inv; s3[2] = D;                             // m in the log2 domain
         }
     } else {
-        float kj[16], vj[16], qi[16], di[16], dk[16], dv[16];
+        float kj[16], vj[16], qv[16], dv16[16], dk[16], dv[16];
         ld16(K + off, kj);
         ld16(Vv + off, vj);
 #pragma unroll
         for (int c = 0; c < 16; ++c) { dk[c] = 0.0f; dv[c] = 0.0f; }
-        if (x < h) {                                                   // keys with x >= h are in nobody's window (the column bound uses h)
-            for (int qy = max(0, y - 2); qy < min(h, y + 3); ++qy)
-#pragma unroll 1
-                for (int qx = max(0, x - 2); qx < min(w, x + 3); ++qx) {
-                    const long long qt = img0 + qy * w + qx;
-                    const size_t qo = (size_t)qt * 128 + head * 16;
-                    ld16(Q + qo, qi);
-                    ld16(dO + qo, di);
-                    const float* s3 = stats + ((size_t)qt * 8 + head) * 3;
-                    const float pij = fast_exp2(scale2 * dot16(qi, kj) - s3[0]) * s3[1];
-                    const float ds = pij * (dot16(di, vj) - s3[2]);
+        const float* bS = tS + (qy * kWaHC + qx) * 6 + hl * 3;
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) { dk[c] += ds * qi[c]; dv[c] += pij * di[c]; }
-                }
+        for (int t = 0; t < 25; ++t) {
+            const int so = (t / 5) * kWaHC + t % 5;
+            lds16(bA + so * kWaRow, qv);
+            lds16(bB + so * kWaRow, dv16);
+            const float pij = fast_exp2(scale2 * dot16(qv, kj) - bS[so * 6]) * bS[so * 6 + 1];     // 1/l = 0 outside the image
+            const float ds = pij * (dot16(dv16, vj) - bS[so * 6 + 2]);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { dk[c] += ds * qv[c]; dv[c] += pij * dv16[c]; }
         }
+        if (!valid) return;
+        const float seen = x < h ? 1.0f : 0.0f;                            // keys with x >= h are in nobody's window (the column bound uses h)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) dk[c] *= scale;
+        for (int c = 0; c < 16; ++c) { dk[c] *= scale * seen; dv[c] *= seen; }
         st16(dK + off, dk);
         st16(dV + off, dv);
     }

@@ -256,6 +256,17 @@ int ang_attn(const TrainCtx& c, const float* QK, const float* Vv, float* O, cons
     return 0;
 }
 
+template <int MODE>
+int win_attn(const TrainCtx& c, const float* Q, const float* K, const float* V, float* O, const float* dO, float* dQ, float* dK, float* dV) {
+    const Dims& d = c.d;
+    const unsigned tiles = (unsigned)(((d.w + kWaTX - 1) / kWaTX) * ((d.h + kWaTY - 1) / kWaTY) * d.B * d.V);
+    int rc;
+    if ((rc = allow_lds(k_win_attn_lds<MODE>, kWaLds, "k_win_attn_lds"))) return rc;
+    k_win_attn_lds<MODE><<<dim3(tiles, 4), 256, kWaLds, c.st>>>(Q, K, V, O, dO, dQ, dK, dV, c.F(c.T.stats), d.h, d.w);
+    LFT_LAUNCH_OK("k_win_attn_lds");
+    return 0;
+}
+
 // ---------------------------------------------------------------------------- forward with tape
 int train_forward(const float* const* P, const float* lr, float* out, float* tape, const Dims& d, int math, hipStream_t st) {
     const TrainLayout T = train_layout(d);
@@ -299,9 +310,7 @@ int train_forward(const float* const* P, const float* lr, float* out, float* tap
         TRY(lin_fwd(c, vw(l, SIN_F), c.F(sp.n), 0, nullptr, c.F(sp.q), N, 0, 4));
         TRY(lin_fwd(c, vw(l, SIN_F), c.F(sp.n), 0, nullptr, c.F(sp.k), N, 4, 4));
         TRY(lin_fwd(c, vw(l, SIN_F), c.F(sp.tok), 0, nullptr, c.F(sp.v), N, 8, 4));
-        k_win_attn<0><<<blocks_for(N * 8, 256), 256, 0, st>>>(c.F(sp.q), c.F(sp.k), c.F(sp.v), c.F(sp.o), nullptr, nullptr, nullptr,
-                                                            nullptr, nullptr, N, d.h, d.w);
-        LFT_LAUNCH_OK("k_win_attn");
+        TRY(win_attn<0>(c, c.F(sp.q), c.F(sp.k), c.F(sp.v), c.F(sp.o), nullptr, nullptr, nullptr, nullptr));
         TRY(lin_fwd(c, vw(l, SOUT_F), c.F(sp.o), 0, c.F(sp.tok), c.F(sp.t1), N));
         TRY(ln_fwd(c, 128, c.F(sp.t1), nullptr, 0, P[pidx(l, S_N2W)], P[pidx(l, S_N2B)], c.F(sp.m), N));
         TRY(lin_fwd(c, vw(l, SFF1_F), c.F(sp.m), 1, nullptr, c.F(sp.hdn), N));
@@ -360,12 +369,8 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
             TRY(ln_bwd(c, 128, c.F(sp.t1), nullptr, 0, P[pidx(l, S_N2W)], h1, h0, h0, g(pidx(l, S_N2W)), g(pidx(l, S_N2B)), N));   // h0 = d t1
             TRY(wgrad(c, h0, 128, c.F(sp.o), 128, 1, g(pidx(l, S_OUT)), 0, N));
             TRY(lin_bwd(c, vw(l, SOUT_B), h0, nullptr, h1, N));                        // h1 = d O
-            k_win_attn<1><<<blocks_for(N * 8, 256), 256, 0, st>>>(c.F(sp.q), c.F(sp.k), c.F(sp.v), nullptr, h1, h2, nullptr, nullptr,
-                                                                c.F(T.stats), N, d.h, d.w);          // h2 = dQ
-            LFT_LAUNCH_OK("k_win_attn");
-            k_win_attn<2><<<blocks_for(N * 8, 256), 256, 0, st>>>(c.F(sp.q), c.F(sp.k), c.F(sp.v), nullptr, h1, nullptr, h3, h4,
-                                                                c.F(T.stats), N, d.h, d.w);          // h3 = dK, h4 = dV
-            LFT_LAUNCH_OK("k_win_attn");
+            TRY(win_attn<1>(c, c.F(sp.q), c.F(sp.k), c.F(sp.v), nullptr, h1, h2, nullptr, nullptr));      // h2 = dQ (+ row stats)
+            TRY(win_attn<2>(c, c.F(sp.q), c.F(sp.k), c.F(sp.v), nullptr, h1, nullptr, h3, h4));           // h3 = dK, h4 = dV
             TRY(wgrad(c, h4, 128, c.F(sp.tok), 128, 1, gin + 256 * 128, 0, N));
             TRY(lin_bwd(c, vw(l, SV_B), h4, h0, h0, N));                               // d tok += dV Wv
             TRY(wgrad(c, h2, 128, c.F(sp.n), 128, 1, gin, 0, N));
