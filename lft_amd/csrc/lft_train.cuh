@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_lin(const LinP p) {
 // MFMA with k = token: A[m = o][k] = dY[t0 + k][o], B[k][n = i] = X[shift(t0 + k)][i]; both operands are read
 // straight from the channels-last tensors (lanes = consecutive channels of one token: 128-byte segments).
 // A wave owns one 32-row block of dY channels, one tap, NI 32-column blocks of X channels and one token chunk.
-// grid: x = chunk, y = (o tile, i group), z = tap.   k_reduce then sums the chunks in a fixed order.
+// grid: x = chunk, y = (o tile, i group), z = tap row (3x3) or 1.   k_reduce then sums the chunks in a fixed order.
 // ------------------------------------------------------------------------------------------
 struct WgP {
     const float* dY; int ldy;
@@ -145,50 +145,65 @@ struct WgP {
     int igroups;
 };
 
-template <int NI, bool M3>
+// TX = 3: the wave owns a whole ROW of taps (dy fixed by blockIdx.z, dx = -1, 0, +1): the dY fragment is loaded (and
+// split) once for three products and the three shifted X rows are neighbours in memory.
+template <int NI, bool M3, int TX>
 __global__ __launch_bounds__(64) void k_wgrad(const WgP p) {
     const int lane = threadIdx.x, r = lane & 31, kh = lane >> 5;
-    const int ot = blockIdx.y / p.igroups, ig = blockIdx.y % p.igroups, tap = blockIdx.z;
+    const int ot = blockIdx.y / p.igroups, ig = blockIdx.y % p.igroups;
     const int o0 = ot * 32, i0 = ig * NI * 32;
     const long long ta = (long long)blockIdx.x * p.chunk_len, tb = min(ta + p.chunk_len, p.N);
     const int hw = p.h * p.w;
-    int dy = 0, dx = 0;
-    if (p.taps == 9) { dy = tap / 3 - 1; dx = tap % 3 - 1; }
-    f32x16 acc[NI];
-    zero_acc<NI>(acc);
+    const int dy = TX == 3 ? (int)blockIdx.z - 1 : 0;
+    f32x16 acc[TX][NI];
+#pragma unroll
+    for (int tx = 0; tx < TX; ++tx) zero_acc<NI>(acc[tx]);
     for (long long t0 = ta; t0 < tb; t0 += 16) {
-        Frag<float> a, b[NI];
+        Frag<float> a, b[TX][NI];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const long long t = t0 + 8 * kh + j;
             const bool in = t < tb;
             const long long tc = in ? t : ta;
             const int pix = (int)(tc % hw), y = pix / p.w, x = pix - y * p.w;
-            const bool ok = in && (y + dy >= 0) && (y + dy < p.h) && (x + dx >= 0) && (x + dx < p.w);
+            const bool okrow = in && (y + dy >= 0) && (y + dy < p.h);
             const float av = p.dY[tc * p.ldy + o0 + r];
-            const float* xr = p.X + (ok ? tc + dy * p.w + dx : tc) * p.ldx + i0 + r;
             if (j < 4) a.lo[j] = in ? av : 0.0f; else a.hi[j - 4] = in ? av : 0.0f;
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const float bv = xr[32 * ni];
-                if (j < 4) b[ni].lo[j] = ok ? bv : 0.0f; else b[ni].hi[j - 4] = ok ? bv : 0.0f;
+            for (int tx = 0; tx < TX; ++tx) {
+                const int dx = TX == 3 ? tx - 1 : 0;
+                const bool ok = okrow && (x + dx >= 0) && (x + dx < p.w);
+                const float* xr = p.X + (ok ? tc + dy * p.w + dx : tc) * p.ldx + i0 + r;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const float bv = xr[32 * ni];
+                    if (j < 4) b[tx][ni].lo[j] = ok ? bv : 0.0f; else b[tx][ni].hi[j - 4] = ok ? bv : 0.0f;
+                }
             }
         }
         if constexpr (M3) {
             const Frag2 a2 = split_frag(a);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) mma3(a2, split_frag(b[ni]), acc[ni]);
+            for (int tx = 0; tx < TX; ++tx)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) mma3(a2, split_frag(b[tx][ni]), acc[tx][ni]);
         } else {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) mma(a, b[ni], acc[ni]);
+            for (int tx = 0; tx < TX; ++tx)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) mma(a, b[tx][ni], acc[tx][ni]);
         }
     }
-    float* dst = p.part + (long long)blockIdx.x * p.wsize + (size_t)tap * p.st;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int tx = 0; tx < TX; ++tx) {
+        const int tap = TX == 3 ? (int)blockIdx.z * 3 + tx : 0;
+        float* dst = p.part + (long long)blockIdx.x * p.wsize + (size_t)tap * p.st;
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            dst[(size_t)(o0 + acc_row(i, kh)) * p.so + (size_t)(i0 + 32 * ni + r) * p.si] = acc[ni][i];
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                dst[(size_t)(o0 + acc_row(i, kh)) * p.so + (size_t)(i0 + 32 * ni + r) * p.si] = acc[tx][ni][i];
+    }
 }
 
 // dst[i] (+)= sum_c part[c*stride + i], in a fixed order (deterministic): block = 64 elements x 4 chunk lanes.

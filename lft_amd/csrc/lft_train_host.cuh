@@ -196,14 +196,19 @@ int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, in
     len = (len + 15) & ~15LL;
     WgP p{dY, Co, X, Ci, c.F(c.T.part), wsize, Ci * taps, taps, 1, Co, Ci, taps, c.d.h, c.d.w, N, len, 1};
     const bool m3 = c.math == LFT_MATH_BF16X3;
-    if (Ci % 128 == 0) {
+    if (taps == 9) {                                  // all 3x3 convolutions of the network have Ci = 64
+        if (Ci != 64) return fail(LFT_ERR_ARG, "wgrad: 3x3 with Ci %d not supported", Ci);
+        p.igroups = 1;
+        const dim3 g((unsigned)nch, (unsigned)(Co / 32), 3u);
+        if (m3) k_wgrad<2, true, 3><<<g, 64, 0, c.st>>>(p); else k_wgrad<2, false, 3><<<g, 64, 0, c.st>>>(p);
+    } else if (Ci % 128 == 0) {
         p.igroups = Ci / 128;
-        const dim3 g((unsigned)nch, (unsigned)(Co / 32 * p.igroups), (unsigned)taps);
-        if (m3) k_wgrad<4, true><<<g, 64, 0, c.st>>>(p); else k_wgrad<4, false><<<g, 64, 0, c.st>>>(p);
+        const dim3 g((unsigned)nch, (unsigned)(Co / 32 * p.igroups), 1u);
+        if (m3) k_wgrad<4, true, 1><<<g, 64, 0, c.st>>>(p); else k_wgrad<4, false, 1><<<g, 64, 0, c.st>>>(p);
     } else {
         p.igroups = Ci / 64;
-        const dim3 g((unsigned)nch, (unsigned)(Co / 32 * p.igroups), (unsigned)taps);
-        if (m3) k_wgrad<2, true><<<g, 64, 0, c.st>>>(p); else k_wgrad<2, false><<<g, 64, 0, c.st>>>(p);
+        const dim3 g((unsigned)nch, (unsigned)(Co / 32 * p.igroups), 1u);
+        if (m3) k_wgrad<2, true, 1><<<g, 64, 0, c.st>>>(p); else k_wgrad<2, false, 1><<<g, 64, 0, c.st>>>(p);
     }
     LFT_LAUNCH_OK("k_wgrad");
     k_reduce<<<blocks_for(wsize, 64), 256, 0, c.st>>>(c.F(c.T.part), nch, wsize, wsize, dW, accumulate);
