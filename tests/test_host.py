@@ -4,6 +4,7 @@ import os
 import re
 from types import SimpleNamespace
 
+import numpy as np
 import pytest
 import torch
 
@@ -70,3 +71,28 @@ def test_size_queries_and_argument_errors():
     with pytest.raises(_lib.LftError, match="not implemented"):
         _lib.packed_bytes(12, 32, 32, 2, _lib.PREC_F32)
     assert _lib.packed_bytes(9, 32, 32, 4, _lib.PREC_BF16) > 2_000_000      # 9x9 = 81 views is supported
+
+
+def test_training_and_metrics_size_queries_and_argument_errors():
+    """The training / metrics entry points validate their arguments before touching the device (no GPU needed)."""
+    from lft_amd import train as T
+    from lft_amd.params import param_table
+    assert T.grad_floats(2) == sum(int(np.prod(s)) for _, s, _ in param_table(64, 2)) == 1_114_240
+    assert T.grad_floats(4) == 1_163_392
+    assert T.tape_bytes(2, 5, 32, 32, 2) > 2 * T.tape_bytes(1, 5, 32, 32, 2) * 0.9
+    L = _lib.lib()
+    n = ctypes.c_size_t(0)
+    assert L.lft_train_grad_floats(3, ctypes.byref(n)) == -2                            # LFT_ERR_SHAPE
+    assert L.lft_train_tape_bytes(1, 5, 32, 32, 3, ctypes.byref(n)) == -2
+    assert L.lft_train_tape_offset(b"no.such.field", 1, 5, 8, 8, 2, ctypes.byref(n)) == -1
+    assert b"unknown tape field" in L.lft_last_error()
+    assert L.lft_train_tape_offset(b"spa3.hdn", 1, 5, 8, 8, 2, ctypes.byref(n)) == 0 and n.value > 0
+    arr = (ctypes.c_void_p * 78)(*([1] * 78))                                            # never dereferenced: rejected first
+    assert L.lft_train_forward(arr, 77, 1, 1, 1, 1, 5, 8, 8, 2, 0, None) == -1
+    assert b"78" in L.lft_last_error()
+    assert L.lft_train_forward(arr, 78, 1, 1, 1, 1, 5, 8, 8, 2, 9, None) == -1
+    assert b"math" in L.lft_last_error()
+    assert L.lft_train_backward(arr, 78, 1, 1, None, 1, 1, 5, 8, 8, 2, 0, None) == -1    # null dout
+    assert L.lft_view_metrics_scratch_bytes(1, 5, 32, 32, ctypes.byref(n)) == 0 and n.value == 25 * 4 * 3 * 8
+    assert L.lft_view_metrics(1, 1, 1, 5, 8, 8, 2.0, 1, 1, 1, None) == -2                 # views smaller than the SSIM window
+    assert L.lft_adam_step(1, 1, 1, 1, 10, 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, None) == -1   # steps count from 1

@@ -11,7 +11,7 @@ def load(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter: continue
             m = re.search(r"(k_[a-z0-9_]+)", r["Kernel_Name"])
-            if m: acc[m.group(1).replace("k_spa_attn_lds", "k_spa_attn")].append(float(r["Counter_Value"]) * 1024.0)
+            if m: acc[m.group(1).replace("k_spa_attn_lds", "k_spa_attn").replace("k_spa_attn_mfma", "k_spa_attn")].append(float(r["Counter_Value"]) * 1024.0)
     return {k: sum(v) / len(v) for k, v in acc.items()}
 F, W = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
 narrow = {"k_assemble", "k_conv0", "k_pack", "k_pe_tables", "k_copy_f32"}
