@@ -119,7 +119,7 @@ def cpu_baseline(seconds: float):
             "sample": f"{n} single-patch forwards (A5, 4x, 32x32 LR, fp32, torch {torch.__version__} CPU ops) in {dt:.1f} s"}
 
 
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_v5_hbm_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_v7_hbm_traffic.json")
 
 
 def traffic_from_profile(kernel: str, args) -> dict:
@@ -130,7 +130,7 @@ def traffic_from_profile(kernel: str, args) -> dict:
     if default and os.path.exists(TRAFFIC_PROFILE):
         k = json.load(open(TRAFFIC_PROFILE))["kernels"].get(kernel)
         if k:
-            return {"traffic": k["total"], "traffic_source": "profiles/r01_v5_hbm_traffic.json"}
+            return {"traffic": k["total"], "traffic_source": "profiles/r01_v7_hbm_traffic.json"}
     return {"traffic": None}
 
 
