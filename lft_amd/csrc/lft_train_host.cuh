@@ -162,16 +162,18 @@ int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int l
             float* Y, int ldy, long long N) {
     const WView& v = c.W.v[view];
     if (nOT <= 0) nOT = v.OT;
-    if (nOT % 2 || (v.taps != 1 && (ot0 || nOT != v.OT))) return fail(LFT_ERR_ARG, "run_lin: bad tile block (view %d)", view);
+    if ((v.taps != 1 && (ot0 || nOT != v.OT))) return fail(LFT_ERR_ARG, "run_lin: bad tile block (view %d)", view);
     LinP p{X, ldx, c.F(c.T.wp) + (v.frag0 + (size_t)ot0 * v.KS) * 512, v.OT, v.KS, R, ldr, Y, ldy, v.taps, flip, act, c.d.h, c.d.w, N};
     const unsigned gx = (unsigned)((N + 127) / 128);
-    if (c.math == LFT_MATH_BF16X3) {
-        if (nOT % 4 == 0) k_lin<4, true><<<dim3(gx, (unsigned)(nOT / 4)), 256, 0, c.st>>>(p);
-        else k_lin<2, true><<<dim3(gx, (unsigned)(nOT / 2)), 256, 0, c.st>>>(p);
-    } else {
-        if (nOT % 4 == 0) k_lin<4, false><<<dim3(gx, (unsigned)(nOT / 4)), 256, 0, c.st>>>(p);
-        else k_lin<2, false><<<dim3(gx, (unsigned)(nOT / 2)), 256, 0, c.st>>>(p);
-    }
+    // output tiles per wave: 4 when that still gives the chip >= 2 waves per SIMD, fewer (more, thinner waves) for small N
+    const long long tiles = (N + 31) / 32;
+    int nt = 4;
+    while (nt > 1 && (nOT % nt || tiles * (nOT / nt) < 2048)) nt >>= 1;
+    const dim3 g(gx, (unsigned)(nOT / nt));
+    const bool m3 = c.math == LFT_MATH_BF16X3;
+    if (nt == 4) { if (m3) k_lin<4, true><<<g, 256, 0, c.st>>>(p); else k_lin<4, false><<<g, 256, 0, c.st>>>(p); }
+    else if (nt == 2) { if (m3) k_lin<2, true><<<g, 256, 0, c.st>>>(p); else k_lin<2, false><<<g, 256, 0, c.st>>>(p); }
+    else { if (m3) k_lin<1, true><<<g, 256, 0, c.st>>>(p); else k_lin<1, false><<<g, 256, 0, c.st>>>(p); }
     LFT_LAUNCH_OK("k_lin");
     return 0;
 }
@@ -190,7 +192,7 @@ int lin_bwd(const TrainCtx& c, int view, const float* dY, const float* R, float*
 int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, int taps, float* dW, int accumulate, long long N) {
     if (Co % 32 || Ci % 64) return fail(LFT_ERR_ARG, "wgrad: Co %d / Ci %d not supported", Co, Ci);
     const long long wsize = (long long)Co * Ci * taps;
-    int nch = (int)std::min<long long>(kWgChunks, std::max<long long>(16, N / 192));   // >= ~192 tokens per chunk: partial traffic stays below the operand traffic
+    int nch = (int)std::min<long long>(kWgChunks, std::max<long long>(16, N / 64));    // >= 64 tokens per chunk: partial traffic stays comparable to the operand traffic
     while (nch > 1 && (size_t)nch * wsize > c.T.part_floats) nch >>= 1;
     long long len = (N + nch - 1) / nch;
     len = (len + 15) & ~15LL;
