@@ -192,7 +192,7 @@ int lin_bwd(const TrainCtx& c, int view, const float* dY, const float* R, float*
 int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, int taps, float* dW, int accumulate, long long N) {
     if (Co % 32 || Ci % 64) return fail(LFT_ERR_ARG, "wgrad: Co %d / Ci %d not supported", Co, Ci);
     const long long wsize = (long long)Co * Ci * taps;
-    int nch = (int)std::min<long long>(kWgChunks, std::max<long long>(16, N / 64));    // >= 64 tokens per chunk: partial traffic stays comparable to the operand traffic
+    int nch = (int)std::min<long long>(kWgChunks, std::max<long long>(16, N / 128));   // >= 128 tokens per chunk: partial traffic stays below the operand traffic
     while (nch > 1 && (size_t)nch * wsize > c.T.part_floats) nch >>= 1;
     long long len = (N + nch - 1) / nch;
     len = (len + 15) & ~15LL;
