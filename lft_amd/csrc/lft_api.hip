@@ -272,6 +272,12 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
 }
 
 void launch_assemble(const float* lr, const float* g, float* out, int B, int A, int h, int w, int s, int with_body, hipStream_t st) {
+    if (with_body) {                                    // tiled gather: 8 x 8 LR mosaic pixels per workgroup
+        const dim3 tg((unsigned)((A * w + 7) / 8), (unsigned)((A * h + 7) / 8), (unsigned)B);
+        if (s == 2) k_assemble_t<2><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w);
+        else k_assemble_t<4><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w);
+        return;
+    }
     const dim3 grid((unsigned)((A * w * s + 255) / 256), (unsigned)(A * h * s), (unsigned)B);
     if (s == 2) k_assemble<2><<<grid, 256, 0, st>>>(lr, g, out, B, A, h, w, with_body);
     else k_assemble<4><<<grid, 256, 0, st>>>(lr, g, out, B, A, h, w, with_body);

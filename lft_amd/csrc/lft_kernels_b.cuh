@@ -716,6 +716,54 @@ __global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ lr, 
     out[((size_t)b * HR_H + Y) * HR_W + X] = v;
 }
 
+// Tiled form of the same gather (the one the forward uses): a workgroup owns an 8 x 8 block of LR mosaic pixels =
+// an 8S x 8S block of output pixels, and stages the (8+2)^2 footprints it can touch in LDS with coalesced 16-byte
+// loads (a footprint is (S+2)^2 contiguous floats) -- every footprint is fetched once per block instead of once per
+// output row that needs it, and the 4-float groups read by neighbouring lanes fall on distinct banks (row stride
+// (S+2)^2 = 36 or 16 floats).  The bicubic taps come from the LR mosaic, which is cache-resident (0.1 MB per patch).
+template <int S>
+__global__ __launch_bounds__(256) void k_assemble_t(const float* __restrict__ lr, const float* __restrict__ G, float* __restrict__ out,
+                                                    int B, int A, int h, int w) {
+    constexpr int TL = 8, HL = TL + 2, GP = (S + 2) * (S + 2), P4 = GP / 4, TS = TL * S;
+    __shared__ __attribute__((aligned(16))) float gs[HL * HL * GP];
+    const int MH = A * h, MW = A * w, HR_W = MW * S, HR_H = MH * S;
+    const int by0 = blockIdx.y * TL, bx0 = blockIdx.x * TL, b = blockIdx.z;
+    const int hw = h * w, V = A * A;
+    const float* Gb = G + (size_t)b * V * hw * GP;
+    for (int pidx = threadIdx.x; pidx < HL * HL * P4; pidx += 256) {
+        const int slot = pidx / P4, part = pidx - slot * P4;
+        const int by = by0 - 1 + slot / HL, bx = bx0 - 1 + slot % HL;
+        f32x4 v = f32x4{0, 0, 0, 0};                                   // outside the mosaic: zero padding of the final conv (LFT.py:43)
+        if (by >= 0 && by < MH && bx >= 0 && bx < MW) {
+            const int vy = by / h, py = by - vy * h, vx = bx / w, px = bx - vx * w;
+            v = load4(Gb + ((size_t)(vy * A + vx) * hw + py * w + px) * GP + part * 4);
+        }
+        *reinterpret_cast<f32x4*>(gs + slot * GP + part * 4) = v;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TS * TS; idx += 256) {
+        const int Yl = idx / TS, Xl = idx - Yl * TS;
+        const int Y = by0 * S + Yl, X = bx0 * S + Xl;
+        if (Y >= HR_H || X >= HR_W) continue;
+        const int a1 = Y / (h * S), a2 = X / (w * S);
+        const float* view = lr + (size_t)b * MH * MW + (size_t)(a1 * h) * MW + a2 * w;
+        float v = bicubic_at(view, MW, h, w, Y - a1 * h * S, X - a2 * w * S, S);
+        const int ql = Yl / S + 1, qc = Xl / S + 1, i = Yl % S, j = Xl % S;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int I = i - S * dy;
+            if (I < -1 || I > S) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int J = j - S * dx;
+                if (J < -1 || J > S) continue;
+                v += gs[((ql + dy) * HL + qc + dx) * GP + (I + 1) * (S + 2) + (J + 1)];
+            }
+        }
+        out[((size_t)b * HR_H + Y) * HR_W + X] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Scene tiling around the hot path (reference utils/utils.py:91-157, driven by test.py:83-101): a whole scene is
 // cut into overlapping A*patch x A*patch mosaics on the GPU, super-resolved as ONE batch, and re-assembled from
