@@ -1,4 +1,6 @@
-"""Per-parameter gradient error of the HIP training step against the fp32 and fp64 CPU oracle (GPU box)."""
+"""Diagnostic (GPU box; test infrastructure, not collected by pytest): per-parameter gradient error of the HIP training
+step against the fp32 and fp64 CPU oracle, and where ReLU pre-activations sit within rounding of a kink.
+  ISEED=1 TOPN=30 python tests/diag_train_grad_report.py"""
 import sys, os
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -14,7 +14,7 @@ import torch
 from lft_amd import _lib, train as T
 from lft_amd.params import deterministic_state, param_table, synthetic_lr
 from oracle import lft_oracle as O
-from oracle.fixtures import sub_indices
+from fixture_util import sub_indices
 
 import gpu_util as G
 
@@ -25,8 +25,8 @@ CASES = [(3, 2, 2, 6, 6), (2, 4, 1, 8, 5), (5, 2, 1, 8, 8), (2, 2, 1, 5, 9),    
          (9, 2, 1, 4, 4), (3, 2, 1, 7, 5), (5, 2, 1, 16, 16)]                    # 81 views; ragged 32-token tiles (315 tokens); 6400 tokens
 # The network is piecewise linear (ReLU, LeakyReLU, |.|): when a pre-activation lies within fp32 rounding of 0, two
 # correct fp32 implementations take different branches and -- at small token counts, where one token is 1/300 of the
-# batch -- whole gradient tensors move by ~1e-3 (torch-fp32 against torch-fp64 shows the same).  tools/
-# train_grad_report.py diagnoses it: with input seed 0, case A3 7x5 has |z| = 1.6e-7 at unit 115 of token 210 in
+# batch -- whole gradient tensors move by ~1e-3 (torch-fp32 against torch-fp64 shows the same).  tests/
+# diag_train_grad_report.py diagnoses it: with input seed 0, case A3 7x5 has |z| = 1.6e-7 at unit 115 of token 210 in
 # spa_trans 1's FFN and exactly that row of feed_forward.1.weight deviates, then everything upstream of it.
 # So gradients are checked two ways:
 #   * exactly: the oracle's autograd is told to take the branches OUR forward took (O.branch_masks, from our tape) and

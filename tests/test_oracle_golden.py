@@ -9,7 +9,7 @@ import torch
 
 from lft_amd.params import deterministic_state, synthetic_lr
 from oracle import lft_oracle as O
-from oracle.fixtures import stats, sub_indices
+from fixture_util import stats, sub_indices
 
 CASES = ["tiny_a5_s2_b2_6x6", "small_a5_s4_b1_8x8", "small_a9_s4_b1_8x8", "rect_a5_s2_b1_8x6", "wide_a2_s2_b1_6x12",
          "cfg1_a5_s2_b1_32x32", "cfg2_a5_s4_b1_32x32"]

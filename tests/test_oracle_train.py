@@ -8,7 +8,7 @@ import torch
 
 from lft_amd.params import deterministic_state, synthetic_lr
 from oracle import lft_oracle as O
-from oracle.fixtures import stats, sub_indices
+from fixture_util import stats, sub_indices
 
 CASES = ["train_a3_s2_b2_6x6", "train_a2_s4_b1_8x5"]
 

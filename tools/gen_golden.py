@@ -22,7 +22,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from lft_amd.params import deterministic_state, synthetic_lr  # noqa: E402
-from oracle.fixtures import stats, sub_indices  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fixture_util import stats, sub_indices  # noqa: E402  (sub-sampling shared with the tests that read the fixtures)
 
 REF_FILE = "/root/reference/model/LFT.py"
 FULL_TAPS = ("feat", "ang0", "spa0", "spa3")  # kept whole on the tiny case only
