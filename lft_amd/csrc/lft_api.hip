@@ -661,8 +661,8 @@ int lft_train_tape_offset(const char* name, int B, int A, int h, int w, int s, s
     } else if (n.size() > 5 && n.compare(0, 3, "spa") == 0 && n[3] >= '0' && n[3] < '0' + kLayers && n[4] == '.') {
         const SpaTape& a = T.spa[layer(n[3])];
         const std::string f = n.substr(5);
-        if (f == "tok") *out_float_offset = a.tok; else if (f == "n") *out_float_offset = a.n; else if (f == "q") *out_float_offset = a.q;
-        else if (f == "k") *out_float_offset = a.k; else if (f == "v") *out_float_offset = a.v; else if (f == "o") *out_float_offset = a.o;
+        if (f == "tok") *out_float_offset = a.tok; else if (f == "n") *out_float_offset = a.n; else if (f == "qk") *out_float_offset = a.qk;
+        else if (f == "v") *out_float_offset = a.v; else if (f == "o") *out_float_offset = a.o;
         else if (f == "t1") *out_float_offset = a.t1; else if (f == "m") *out_float_offset = a.m; else if (f == "hdn") *out_float_offset = a.hdn;
         else if (f == "t2") *out_float_offset = a.t2; else if (f == "y") *out_float_offset = a.y; else if (f == "petok") *out_float_offset = a.petok;
         else return fail(LFT_ERR_ARG, "unknown tape field %s", name);

@@ -77,6 +77,7 @@ struct LinP {
     const float* Wp; int OT, KS;      // packed fragments (k_pack, natural k order): frag (tap, ot, ks) at ((tap*OT + ot)*KS + ks)
     const float* R; int ldr;          // optional: accumulator initialised with R (residual, or Y itself to accumulate)
     float* Y; int ldy;
+    const float* M; int ldm, mact;    // optional backward-of-activation epilogue: Y = acc * act'(M), M = the saved activation OUTPUT (mact 1 relu, 2 lrelu)
     int taps, flip, act;              // act: 0 none, 1 relu, 2 leaky relu 0.2
     int h, w;
     long long N;
@@ -123,6 +124,14 @@ __global__ __launch_bounds__(256) void k_lin(const LinP p) {
                 const float v = acc[nt][i];
                 acc[nt][i] = v > 0.0f ? v : (p.act == 1 ? 0.0f : 0.2f * v);
             }
+    }
+    if (p.M) {                                                           // dZ = dY * act'(Z), sign(Z) read off the saved act(Z)
+        f32x16 mk[NT];
+        load_tile<NT, float>(p.M + t0 * p.ldm + o0, nvalid, lane, mk, scr, (size_t)p.ldm * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = mk[nt][i] > 0.0f ? acc[nt][i] : (p.mact == 1 ? 0.0f : 0.2f * acc[nt][i]);
     }
     store_tile<NT, float>(p.Y + t0 * p.ldy + o0, nvalid, lane, acc, scr, (size_t)p.ldy * 4);
 }
@@ -524,12 +533,12 @@ constexpr int kWaTY = 8, kWaTX = 16, kWaHR = kWaTY + 4, kWaHC = kWaTX + 4, kWaSl
 constexpr int kWaTile = kWaSlots * kWaRow;                     // floats per staged tensor
 constexpr size_t kWaLds = (size_t)(2 * kWaTile + kWaSlots * 6) * sizeof(float);
 
-LFT_DEV void wa_stage(const float* __restrict__ src, float* lds, long long img0, int y0, int x0, int hp, int h, int w) {
+LFT_DEV void wa_stage(const float* __restrict__ src, int ld, float* lds, long long img0, int y0, int x0, int hp, int h, int w) {
     for (int idx = threadIdx.x; idx < kWaSlots * 8; idx += 256) {
         const int slot = idx >> 3, piece = idx & 7;
         const int gy = y0 - 2 + slot / kWaHC, gx = x0 - 2 + slot % kWaHC;
         const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
-        const f32x4 v = load4(src + (size_t)(in ? img0 + gy * w + gx : img0) * 128 + hp * 32 + piece * 4);
+        const f32x4 v = load4(src + (size_t)(in ? img0 + gy * w + gx : img0) * ld + hp * 32 + piece * 4);
         *reinterpret_cast<f32x4*>(lds + slot * kWaRow + piece * 4) = in ? v : f32x4{0, 0, 0, 0};
     }
 }
@@ -545,7 +554,8 @@ template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_win_attn_lds(const float* __restrict__ Q, const float* __restrict__ K,
                                                          const float* __restrict__ Vv, float* __restrict__ O,
                                                          const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ dK,
-                                                         float* __restrict__ dV, float* __restrict__ stats, int h, int w) {
+                                                         float* __restrict__ dV, float* __restrict__ stats, int h, int w, int ldq) {
+    // Q, K, dQ, dK rows are ldq floats apart (they are the two halves of one [N][256] tensor); V, O, dO, dV rows 128.
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float* tA = wsm;                        // K (MODE 0/1) or Q (MODE 2)
     float* tB = wsm + kWaTile;              // V (MODE 0/1) or dO (MODE 2)
@@ -560,10 +570,10 @@ __global__ __launch_bounds__(256, 2) void k_win_attn_lds(const float* __restrict
     const int y = y0 + qy, x = x0 + qx;
     const bool valid = y < h && x < w;
     const long long tok = img0 + min(y, h - 1) * w + min(x, w - 1);
-    const size_t off = (size_t)tok * 128 + hp * 32 + hl * 16;
+    const size_t off = (size_t)tok * 128 + hp * 32 + hl * 16, offq = (size_t)tok * ldq + hp * 32 + hl * 16;
     const float scale = 0.25f, scale2 = 0.25f * LFT_LOG2E;
-    wa_stage(MODE == 2 ? Q : K, tA, img0, y0, x0, hp, h, w);
-    wa_stage(MODE == 2 ? dO : Vv, tB, img0, y0, x0, hp, h, w);
+    wa_stage(MODE == 2 ? Q : K, ldq, tA, img0, y0, x0, hp, h, w);
+    wa_stage(MODE == 2 ? dO : Vv, 128, tB, img0, y0, x0, hp, h, w);
     if (MODE == 2) {
         for (int idx = threadIdx.x; idx < kWaSlots * 6; idx += 256) {
             const int slot = idx / 6, e = idx % 6;
@@ -578,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void k_win_attn_lds(const float* __restrict
     if (MODE == 0 || MODE == 1) {
         const int wy0 = max(0, y - 2), wy1 = min(h, y + 3), wx0 = max(0, x - 2), wx1 = min(min(h, x + 3), w);   // LFT.py:150-160 (sic)
         float q[16], kv[16], vv[16], dov[16], sc[25];
-        ld16(Q + off, q);
+        ld16(Q + offq, q);
         if (MODE == 1) ld16(dO + off, dov);
         float m = -INFINITY;
 #pragma unroll
@@ -619,13 +629,13 @@ __global__ __launch_bounds__(256, 2) void k_win_attn_lds(const float* __restrict
             D *= inv;
 #pragma unroll
             for (int c = 0; c < 16; ++c) o[c] = scale * inv * (o[c] - D * a2[c]);
-            st16(dQ + off, o);
+            st16(dQ + offq, o);
             float* s3 = stats + ((size_t)tok * 8 + hp * 2 + hl) * 3;
             s3[0] = m; s3[1] = inv; s3[2] = D;                             // m in the log2 domain
         }
     } else {
         float kj[16], vj[16], qv[16], dv16[16], dk[16], dv[16];
-        ld16(K + off, kj);
+        ld16(K + offq, kj);
         ld16(Vv + off, vj);
 #pragma unroll
         for (int c = 0; c < 16; ++c) { dk[c] = 0.0f; dv[c] = 0.0f; }
@@ -644,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void k_win_attn_lds(const float* __restrict
         const float seen = x < h ? 1.0f : 0.0f;                            // keys with x >= h are in nobody's window (the column bound uses h)
 #pragma unroll
         for (int c = 0; c < 16; ++c) { dk[c] *= scale * seen; dv[c] *= seen; }
-        st16(dK + off, dk);
+        st16(dK + offq, dk);
         st16(dV + off, dv);
     }
 }

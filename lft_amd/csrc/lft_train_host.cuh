@@ -34,7 +34,7 @@ inline ParamInfo param_info(int s) {
 
 // ---- packed weight views: every matrix the step multiplies by, in both orientations, as k_pack fragment streams ----
 enum { VW_CONV_F = 0, VW_CONV_B = 3, VW_LAYER0 = 6, VW_PER_LAYER = 24, VW_UP_F = VW_LAYER0 + 4 * VW_PER_LAYER, VW_UP_B, VW_COUNT };
-enum { MLP_F = 0, MLP_B, SIN_F, SQ_B, SK_B, SV_B, SOUT_F, SOUT_B, SFF1_F, SFF1_B, SFF2_F, SFF2_B, SLIN_F, SLIN_B,
+enum { MLP_F = 0, MLP_B, SIN_F, SQK_B, SUNUSED, SV_B, SOUT_F, SOUT_B, SFF1_F, SFF1_B, SFF2_F, SFF2_B, SLIN_F, SLIN_B,
        AIN_F, AQK_B, AV_B, AOUT_F, AOUT_B, AFF1_F, AFF1_B, AFF2_F, AFF2_B };
 inline int vw(int l, int which) { return VW_LAYER0 + VW_PER_LAYER * l + which; }
 struct WView { size_t frag0 = 0; int OT = 0, KS = 0, taps = 0; };
@@ -60,8 +60,7 @@ WViews build_views(const float* const* P, int s, std::vector<PackOp>* ops) {
         add(vw(l, MLP_F), src(pidx(l, S_MLP)), 128, 64, 9, 576, 9, 0, 1);
         add(vw(l, MLP_B), src(pidx(l, S_MLP)), 64, 128, 9, 9, 576, 0, 1);
         fwd(vw(l, SIN_F), src(pidx(l, S_INPROJ)), 384, 128);
-        bwd(vw(l, SQ_B), src(pidx(l, S_INPROJ)), 128, 128, 0);
-        bwd(vw(l, SK_B), src(pidx(l, S_INPROJ)), 128, 128, 128);
+        bwd(vw(l, SQK_B), src(pidx(l, S_INPROJ)), 256, 128, 0);        // (Wq | Wk)^T: d n = [dQ | dK] [Wq ; Wk]
         bwd(vw(l, SV_B), src(pidx(l, S_INPROJ)), 128, 128, 256);
         fwd(vw(l, SOUT_F), src(pidx(l, S_OUT)), 128, 128); bwd(vw(l, SOUT_B), src(pidx(l, S_OUT)), 128, 128);
         fwd(vw(l, SFF1_F), src(pidx(l, S_FF1)), 256, 128); bwd(vw(l, SFF1_B), src(pidx(l, S_FF1)), 256, 128);
@@ -80,7 +79,7 @@ WViews build_views(const float* const* P, int s, std::vector<PackOp>* ops) {
 
 // ---- tape: everything the backward pass re-reads (floats, offsets in floats) ----
 struct AngTape { size_t n, qk, v, o, t1, m, hdn, y; };
-struct SpaTape { size_t petok, tok, n, q, k, v, o, t1, m, hdn, t2, y; };
+struct SpaTape { size_t petok, tok, n, qk, v, o, t1, m, hdn, t2, y; };      // qk = [N][256]: Q | K
 struct TrainLayout {
     size_t wp;                                   // packed weight views (build_views order), 512 floats per fragment
     size_t pe_ang, pe_spa, x0, c1, c2, c3, feat;
@@ -88,7 +87,7 @@ struct TrainLayout {
     SpaTape spa[kLayers];
     size_t body, act, skip;                      // act = lrelu(U) [N, 64 s^2]; skip = bicubic(lr)
     // backward scratch
-    size_t g64[5], g128[5], g256, gu, stats, dpetok, part, pgb;
+    size_t g64[5], g128[4], g256, gu, stats, dpetok, part, pgb;
     size_t part_floats, total;                   // total in floats
 };
 constexpr int kWgChunks = 512;                   // token chunks of a weight-gradient launch
@@ -109,14 +108,14 @@ TrainLayout train_layout(const Dims& d) {
         a.m = take(n * 64); a.hdn = take(n * 128); a.y = take(n * 64);
         SpaTape& sp = T.spa[l];
         sp.petok = take((size_t)d.hw * 128);
-        sp.tok = take(n * 128); sp.n = take(n * 128); sp.q = take(n * 128); sp.k = take(n * 128); sp.v = take(n * 128);
+        sp.tok = take(n * 128); sp.n = take(n * 128); sp.qk = take(n * 256); sp.v = take(n * 128);
         sp.o = take(n * 128); sp.t1 = take(n * 128); sp.m = take(n * 128); sp.hdn = take(n * 256); sp.t2 = take(n * 128);
         sp.y = take(n * 64);
     }
     T.body = take(n * 64); T.act = take(n * 64 * ss);
     T.skip = take((size_t)d.B * d.A * d.h * d.s * d.A * d.w * d.s);
     for (int i = 0; i < 5; ++i) T.g64[i] = take(n * 64);
-    for (int i = 0; i < 5; ++i) T.g128[i] = take(n * 128);
+    for (int i = 0; i < 4; ++i) T.g128[i] = take(n * 128);
     T.g256 = take(n * 256); T.gu = take(n * 64 * ss);
     T.stats = take(n * 8 * 3); T.dpetok = take((size_t)d.hw * 128);
     T.part_floats = std::max((size_t)kWgChunks * 128 * 576, (size_t)kTailWaves * 576);
@@ -159,11 +158,11 @@ struct TrainCtx {
 
 // Y[N][ldy cols o0..] = act(X W(view)^T) (+R).  ot0 / nOT select a block of the view's output tiles (taps == 1 only).
 int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int ldx, int flip, int act, const float* R, int ldr,
-            float* Y, int ldy, long long N) {
+            float* Y, int ldy, long long N, const float* M = nullptr, int mact = 0) {
     const WView& v = c.W.v[view];
     if (nOT <= 0) nOT = v.OT;
     if ((v.taps != 1 && (ot0 || nOT != v.OT))) return fail(LFT_ERR_ARG, "run_lin: bad tile block (view %d)", view);
-    LinP p{X, ldx, c.F(c.T.wp) + (v.frag0 + (size_t)ot0 * v.KS) * 512, v.OT, v.KS, R, ldr, Y, ldy, v.taps, flip, act, c.d.h, c.d.w, N};
+    LinP p{X, ldx, c.F(c.T.wp) + (v.frag0 + (size_t)ot0 * v.KS) * 512, v.OT, v.KS, R, ldr, Y, ldy, M, ldy, mact, v.taps, flip, act, c.d.h, c.d.w, N};
     const unsigned gx = (unsigned)((N + 127) / 128);
     // output tiles per wave: 4 when that still gives the chip >= 2 waves per SIMD, fewer (more, thinner waves) for small N
     const long long tiles = (N + 31) / 32;
@@ -184,9 +183,10 @@ int lin_fwd(const TrainCtx& c, int view, const float* X, int act, const float* R
     return run_lin(c, view, ot0, nOT, X, v.KS * 16, 0, act, R, Co, Y, Co, N);
 }
 // Input gradient through a transposed view: dX = dY W (+R); 3x3 convs flip their taps
-int lin_bwd(const TrainCtx& c, int view, const float* dY, const float* R, float* dX, long long N) {
+// (M, mact): dX is additionally multiplied by act'(.) read off the saved activation output M (same shape as dX)
+int lin_bwd(const TrainCtx& c, int view, const float* dY, const float* R, float* dX, long long N, const float* M = nullptr, int mact = 0) {
     const WView& v = c.W.v[view];
-    return run_lin(c, view, 0, 0, dY, v.KS * 16, 1, 0, R, v.OT * 32, dX, v.OT * 32, N);
+    return run_lin(c, view, 0, 0, dY, v.KS * 16, 1, 0, R, v.OT * 32, dX, v.OT * 32, N, M, mact);
 }
 // weight gradient of either: dW (+)= dY^T X  (taps = 1 or 9)
 int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, int taps, float* dW, int accumulate, long long N) {
@@ -264,12 +264,12 @@ int ang_attn(const TrainCtx& c, const float* QK, const float* Vv, float* O, cons
 }
 
 template <int MODE>
-int win_attn(const TrainCtx& c, const float* Q, const float* K, const float* V, float* O, const float* dO, float* dQ, float* dK, float* dV) {
+int win_attn(const TrainCtx& c, const float* Q, const float* K, const float* V, float* O, const float* dO, float* dQ, float* dK, float* dV) {   // Q | K and dQ | dK: [N][256]
     const Dims& d = c.d;
     const unsigned tiles = (unsigned)(((d.w + kWaTX - 1) / kWaTX) * ((d.h + kWaTY - 1) / kWaTY) * d.B * d.V);
     int rc;
     if ((rc = allow_lds(k_win_attn_lds<MODE>, kWaLds, "k_win_attn_lds"))) return rc;
-    k_win_attn_lds<MODE><<<dim3(tiles, 4), 256, kWaLds, c.st>>>(Q, K, V, O, dO, dQ, dK, dV, c.F(c.T.stats), d.h, d.w);
+    k_win_attn_lds<MODE><<<dim3(tiles, 4), 256, kWaLds, c.st>>>(Q, K, V, O, dO, dQ, dK, dV, c.F(c.T.stats), d.h, d.w, 256);
     LFT_LAUNCH_OK("k_win_attn_lds");
     return 0;
 }
@@ -314,10 +314,9 @@ int train_forward(const float* const* P, const float* lr, float* out, float* tap
         TRY(lin_fwd(c, vw(l, MLP_F), x, 0, nullptr, c.F(sp.tok), N));
         TRY(lin_fwd(c, vw(l, MLP_F), c.F(T.pe_spa), 0, nullptr, c.F(sp.petok), d.hw));   // LFT.py:180
         TRY(ln_fwd(c, 128, c.F(sp.tok), c.F(sp.petok), 2, P[pidx(l, S_N1W)], P[pidx(l, S_N1B)], c.F(sp.n), N));
-        TRY(lin_fwd(c, vw(l, SIN_F), c.F(sp.n), 0, nullptr, c.F(sp.q), N, 0, 4));
-        TRY(lin_fwd(c, vw(l, SIN_F), c.F(sp.n), 0, nullptr, c.F(sp.k), N, 4, 4));
+        TRY(lin_fwd(c, vw(l, SIN_F), c.F(sp.n), 0, nullptr, c.F(sp.qk), N, 0, 8));                 // Q | K in one pass over n
         TRY(lin_fwd(c, vw(l, SIN_F), c.F(sp.tok), 0, nullptr, c.F(sp.v), N, 8, 4));
-        TRY(win_attn<0>(c, c.F(sp.q), c.F(sp.k), c.F(sp.v), c.F(sp.o), nullptr, nullptr, nullptr, nullptr));
+        TRY(win_attn<0>(c, c.F(sp.qk), c.F(sp.qk) + 128, c.F(sp.v), c.F(sp.o), nullptr, nullptr, nullptr, nullptr));
         TRY(lin_fwd(c, vw(l, SOUT_F), c.F(sp.o), 0, c.F(sp.tok), c.F(sp.t1), N));
         TRY(ln_fwd(c, 128, c.F(sp.t1), nullptr, 0, P[pidx(l, S_N2W)], P[pidx(l, S_N2B)], c.F(sp.m), N));
         TRY(lin_fwd(c, vw(l, SFF1_F), c.F(sp.m), 1, nullptr, c.F(sp.hdn), N));
@@ -347,7 +346,7 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
     int rc;
     auto g = [&](int idx) { return G + pi.off[idx]; };
     float *gskip = c.F(T.g64[0]), *ga = c.F(T.g64[1]), *gb = c.F(T.g64[2]), *t64a = c.F(T.g64[3]), *t64b = c.F(T.g64[4]);
-    float *h0 = c.F(T.g128[0]), *h1 = c.F(T.g128[1]), *h2 = c.F(T.g128[2]), *h3 = c.F(T.g128[3]), *h4 = c.F(T.g128[4]);
+    float *h0 = c.F(T.g128[0]), *h1 = c.F(T.g128[1]), *h2 = c.F(T.g128[2]), *h4 = c.F(T.g128[3]);
     float* g256 = c.F(T.g256);
     // ---- up-sampler tail ----
     {
@@ -369,21 +368,18 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
             TRY(wgrad(c, dy, 64, c.F(sp.t2), 128, 1, g(pidx(l, S_LIN)), 0, N));
             TRY(lin_bwd(c, vw(l, SLIN_B), dy, nullptr, h0, N));                         // d t2
             TRY(wgrad(c, h0, 128, c.F(sp.hdn), 256, 1, g(pidx(l, S_FF2)), 0, N));
-            TRY(lin_bwd(c, vw(l, SFF2_B), h0, nullptr, g256, N));                      // d hdn
-            TRY(act_bwd(c, g256, c.F(sp.hdn), g256, N * 256, 1));
+            TRY(lin_bwd(c, vw(l, SFF2_B), h0, nullptr, g256, N, c.F(sp.hdn), 1));      // d (W1 m) = d hdn * relu'()
             TRY(wgrad(c, g256, 256, c.F(sp.m), 128, 1, g(pidx(l, S_FF1)), 0, N));
             TRY(lin_bwd(c, vw(l, SFF1_B), g256, nullptr, h1, N));                      // d m
             TRY(ln_bwd(c, 128, c.F(sp.t1), nullptr, 0, P[pidx(l, S_N2W)], h1, h0, h0, g(pidx(l, S_N2W)), g(pidx(l, S_N2B)), N));   // h0 = d t1
             TRY(wgrad(c, h0, 128, c.F(sp.o), 128, 1, g(pidx(l, S_OUT)), 0, N));
             TRY(lin_bwd(c, vw(l, SOUT_B), h0, nullptr, h1, N));                        // h1 = d O
-            TRY(win_attn<1>(c, c.F(sp.q), c.F(sp.k), c.F(sp.v), nullptr, h1, h2, nullptr, nullptr));      // h2 = dQ (+ row stats)
-            TRY(win_attn<2>(c, c.F(sp.q), c.F(sp.k), c.F(sp.v), nullptr, h1, nullptr, h3, h4));           // h3 = dK, h4 = dV
+            TRY(win_attn<1>(c, c.F(sp.qk), c.F(sp.qk) + 128, c.F(sp.v), nullptr, h1, g256, nullptr, nullptr));        // g256 = [dQ | . ] (+ row stats)
+            TRY(win_attn<2>(c, c.F(sp.qk), c.F(sp.qk) + 128, c.F(sp.v), nullptr, h1, nullptr, g256 + 128, h4));      // g256 = [dQ | dK], h4 = dV
             TRY(wgrad(c, h4, 128, c.F(sp.tok), 128, 1, gin + 256 * 128, 0, N));
             TRY(lin_bwd(c, vw(l, SV_B), h4, h0, h0, N));                               // d tok += dV Wv
-            TRY(wgrad(c, h2, 128, c.F(sp.n), 128, 1, gin, 0, N));
-            TRY(wgrad(c, h3, 128, c.F(sp.n), 128, 1, gin + 128 * 128, 0, N));
-            TRY(lin_bwd(c, vw(l, SQ_B), h2, nullptr, h1, N));
-            TRY(lin_bwd(c, vw(l, SK_B), h3, h1, h1, N));                               // h1 = d n
+            TRY(wgrad(c, g256, 256, c.F(sp.n), 128, 1, gin, 0, N));                    // rows 0..255 of in_proj: Wq, Wk
+            TRY(lin_bwd(c, vw(l, SQK_B), g256, nullptr, h1, N));                       // h1 = d n
             TRY(ln_bwd(c, 128, c.F(sp.tok), c.F(sp.petok), 2, P[pidx(l, S_N1W)], h1, nullptr, h2, g(pidx(l, S_N1W)), g(pidx(l, S_N1B)), N));  // h2 = d(tok+pe)
             k_sum_images<<<blocks_for((long long)d.hw * 128, 256), 256, 0, st>>>(h2, nimg, (long long)d.hw * 128, c.F(T.dpetok));
             LFT_LAUNCH_OK("k_sum_images");
@@ -400,8 +396,7 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
             const float* xin = l == 0 ? c.F(T.feat) : c.F(T.spa[l - 1].y);
             float* gin = g(pidx(l, A_INPROJ));
             TRY(wgrad(c, ga, 64, c.F(a.hdn), 128, 1, g(pidx(l, A_FF2)), 0, N));
-            TRY(lin_bwd(c, vw(l, AFF2_B), ga, nullptr, h0, N));                         // d hdn
-            TRY(act_bwd(c, h0, c.F(a.hdn), h0, N * 128, 1));
+            TRY(lin_bwd(c, vw(l, AFF2_B), ga, nullptr, h0, N, c.F(a.hdn), 1));         // d (W1 m) = d hdn * relu'()
             TRY(wgrad(c, h0, 128, c.F(a.m), 64, 1, g(pidx(l, A_FF1)), 0, N));
             TRY(lin_bwd(c, vw(l, AFF1_B), h0, nullptr, t64a, N));                       // d m
             TRY(ln_bwd(c, 64, c.F(a.t1), nullptr, 0, P[pidx(l, A_N2W)], t64a, ga, gb, g(pidx(l, A_N2W)), g(pidx(l, A_N2B)), N));   // gb = d t1
@@ -421,11 +416,9 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
     TRY(add_to(c, gb, gskip, N * 64));
     TRY(act_bwd(c, gb, c.F(T.c3), ga, N * 64, 2));                                                   // d z3
     TRY(wgrad(c, ga, 64, c.F(T.c2), 64, 9, g(P_CONV + 2), 0, N));
-    TRY(lin_bwd(c, VW_CONV_B + 2, ga, nullptr, gskip, N));                                  // d c2
-    TRY(act_bwd(c, gskip, c.F(T.c2), gskip, N * 64, 2));
+    TRY(lin_bwd(c, VW_CONV_B + 2, ga, nullptr, gskip, N, c.F(T.c2), 2));                    // d z2 = d c2 * lrelu'()
     TRY(wgrad(c, gskip, 64, c.F(T.c1), 64, 9, g(P_CONV + 1), 0, N));
-    TRY(lin_bwd(c, VW_CONV_B + 1, gskip, nullptr, ga, N));                                  // d c1
-    TRY(act_bwd(c, ga, c.F(T.c1), ga, N * 64, 2));
+    TRY(lin_bwd(c, VW_CONV_B + 1, gskip, nullptr, ga, N, c.F(T.c1), 2));                    // d z1 = d c1 * lrelu'()
     TRY(wgrad(c, ga, 64, c.F(T.x0), 64, 9, g(P_CONV + 0), 0, N));
     TRY(lin_bwd(c, VW_CONV_B + 0, ga, gb, gb, N));                                          // d x0 = d feat + conv path
     {
