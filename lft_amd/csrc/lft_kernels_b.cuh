@@ -562,6 +562,8 @@ __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa2(const T* __restrict__
     const int nvalid = (int)max(0LL, min(32LL, ntok - t0));
     const long long tb = min(t0, ntok - 1);
     char* scr = smem + WRing<T, kSpaChunk>::LDS_BYTES + 1024 + wave * TileIO<4, T>::BYTES;   // wave-private tile I/O scratch
+    WRing<T, kSpaChunk> ring;
+    ring.init(ws, smem, 176);                 // first: the weight DMA is in flight while the activation tiles are fetched
     f32x16 t[4], n[4];
     load_tile<4, T>(TOK + tb * 128, nvalid, lane, t, scr);
     Frag<T> f[8];
@@ -570,8 +572,6 @@ __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa2(const T* __restrict__
     if (SKIP) load_tile<2, T>(skip + tb * 64, nvalid, lane, sk, scr);
     float* lds_ln = reinterpret_cast<float*>(smem + WRing<T, kSpaChunk>::LDS_BYTES);
     params_store(lds_ln, 256, params_load(ln + 256, 256));            // feed_forward.0.{weight,bias}; the tile loads above were waited for anyway; published by the first ring barrier
-    WRing<T, kSpaChunk> ring;
-    ring.init(ws, smem, 176);
     linear_ring<4, 8, T>(ring, f, t);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] = t[nt];
@@ -620,10 +620,10 @@ __global__ __launch_bounds__(256) void k_up(const T* __restrict__ X, const T* __
     const long long t0 = tok_raw - r;
     const int nvalid = (int)max(0LL, min(32LL, ntok - t0));
     char* scr = smem + WRing<T, kUpChunk>::LDS_BYTES + (threadIdx.x >> 6) * TileIO<2, T>::BYTES;
+    WRing<T, kUpChunk> ring;
+    ring.init(ws, smem, nchunk * (4 + 2 * GT));         // first: the weight DMA is in flight while the tile is fetched
     f32x16 x[2];
     load_tile<2, T>(X + min(t0, ntok - 1) * 64, nvalid, lane, x, scr);
-    WRing<T, kUpChunk> ring;
-    ring.init(ws, smem, nchunk * (4 + 2 * GT));
     Frag<T> xf[4];
     acc_frags<2, T>(x, xf);
     f32x16 g[GT];
