@@ -55,6 +55,38 @@ def test_batch_independence_cfg2():
     assert not torch.isnan(full).any()
 
 
+@pytest.mark.parametrize("A,s,B,h,w", [(5, 4, 3, 64, 64), (9, 4, 2, 32, 32)], ids=["cfg4_64x64", "cfg5_9x9"])
+def test_full_size_properties_cfg4_cfg5(A, s, B, h, w):
+    """BASELINE configs[3] (64x64 LR views) and configs[4] (9x9 views) at full view size, where the CPU oracle is too slow
+    to be the checker: size-independent properties instead -- batch independence and permutation equivariance
+    (bit-exact), the fp32 and bf16 paths agreeing to bf16 accuracy, and the network reducing to its bicubic skip when
+    the last convolution's weights are zero (the skip path is checked against the oracle at small sizes)."""
+    net = make_net(A, s, 1, "default", "bf16")
+    lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=4)).to("cuda:0")
+    perm = list(range(B))[::-1]
+    with torch.no_grad():
+        full = net(lr)
+        single = torch.cat([net(lr[i:i + 1]) for i in range(B)])
+        rev = net(lr[perm])
+    assert full.shape == (B, 1, A * h * s, A * w * s) and not torch.isnan(full).any()
+    assert torch.equal(full, single) and torch.equal(rev, full[perm])
+    ref32 = make_net(A, s, 1, "default", "fp32")
+    with torch.no_grad():
+        y32 = ref32(lr[:1])
+    rel = float((full[:1] - y32).abs().max() / y32.abs().max())
+    print(f"A{A} {h}x{w}: bf16 vs fp32 path rel max {rel:.2e}")
+    assert rel <= 5e-3
+    with torch.no_grad():
+        dict(ref32.named_parameters())["upsampling.3.weight"].zero_()
+        skip_only = ref32(lr[:1])
+    from lft_amd import _lib
+    bic = torch.empty_like(skip_only)
+    _lib.check(_lib.lib().lft_bicubic_fwd(lr[:1].contiguous().data_ptr(), bic.data_ptr(), 1, A, h, w, s,
+                                          torch.cuda.current_stream().cuda_stream), "lft_bicubic_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(skip_only, bic)
+
+
 def test_loss_and_errors():
     from model import LFT
     a = torch.rand(2, 1, 8, 8, device="cuda:0")
