@@ -304,14 +304,15 @@ int init_features(const void* packed, const PackedLayout& L, const float* lr, T*
 template <typename T, int CT>
 int ang_multi(const void* packed, const PackedLayout& L, int l, const T* in, T* out, const Dims& d, hipStream_t st) {
     constexpr bool WLDS = sizeof(T) == 2;                                   // fp32 weights (128 KiB) stay in L2
+    constexpr int NG = (sizeof(T) == 2 && CT <= 3) ? 2 : 1;                 // positions per workgroup (they share the LDS weights)
     constexpr size_t FB = 1024 * FragInfo<T>::PIECES;
-    const size_t lds = (WLDS ? 64 * FB : 0) + 1024 + (size_t)CT * 8 * FB;
+    const size_t lds = (WLDS ? 64 * FB : 0) + 1024 + (size_t)NG * CT * 8 * FB + (size_t)NG * CT * TileIO<2, T>::BYTES;
     const int npix = d.B * d.hw;
     int rc;
-    if ((rc = allow_lds(k_ang_multi<T, CT, WLDS>, lds, "k_ang_multi"))) return rc;
-    const unsigned grid = std::min<unsigned>((unsigned)npix, 256u * (unsigned)std::max<size_t>(1, kMaxLds / lds));
-    k_ang_multi<T, CT, WLDS><<<grid, 64 * CT, lds, st>>>(in, out, at<T>(packed, L.s_ang[l]), at<float>(packed, L.ln_ang[l]),
-                                                         at<float>(packed, L.ang_pe), d.V, d.hw, npix);
+    if ((rc = allow_lds(k_ang_multi<T, CT, WLDS, NG>, lds, "k_ang_multi"))) return rc;
+    const unsigned grid = std::min<unsigned>(blocks_for(npix, NG), 256u * (unsigned)std::max<size_t>(1, kMaxLds / lds));
+    k_ang_multi<T, CT, WLDS, NG><<<grid, 64 * CT * NG, lds, st>>>(in, out, at<T>(packed, L.s_ang[l]), at<float>(packed, L.ln_ang[l]),
+                                                                 at<float>(packed, L.ang_pe), d.V, d.hw, npix);
     LFT_LAUNCH_OK("k_ang");
     return 0;
 }

@@ -357,20 +357,24 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
 // per head CT score tiles (softmax over up to 32*CT keys: registers + one lane^32 exchange) and 2*CT P.V MFMAs.
 // WLDS: weights LDS-resident (bf16); the fp32 parity build reads them from L2 (128 KiB would not leave room).
 // ------------------------------------------------------------------------------------------
-template <typename T, int CT, bool WLDS>
-__global__ __launch_bounds__(64 * CT) void k_ang_multi(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ ws,
-                                                       const float* __restrict__ ln, const float* __restrict__ pe,
-                                                       int V, int hw, int npix) {
+// NG positions share one workgroup (NG * CT waves) and therefore one LDS copy of the weights: more waves per CU for the
+// same LDS (9x9, bf16: 2 x 3 waves and 113 KiB instead of 3 waves and 89 KiB).  All groups run the loop in lock-step.
+template <typename T, int CT, bool WLDS, int NG>
+__global__ __launch_bounds__(64 * CT * NG) void k_ang_multi(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ ws,
+                                                            const float* __restrict__ ln, const float* __restrict__ pe,
+                                                            int V, int hw, int npix) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int FB = 1024 * FragInfo<T>::PIECES;
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave_all / CT, wave = wave_all % CT;             // position group, column tile inside the position
     char* lds_w = smem;                                            // 64 weight fragments when WLDS
     float* lds_ln = reinterpret_cast<float*>(smem + (WLDS ? 64 * FB : 0));
-    char* lds_kv = reinterpret_cast<char*>(lds_ln) + 1024;         // [CT][8] fragments: K (nt, s) then V (nt, s)
+    char* lds_kv = reinterpret_cast<char*>(lds_ln) + 1024 + (size_t)grp * CT * 8 * FB;   // per group [CT][8] fragments: K (nt, s) then V (nt, s)
+    char* scr = reinterpret_cast<char*>(lds_ln) + 1024 + (size_t)NG * CT * 8 * FB + wave_all * TileIO<2, T>::BYTES;   // wave-private tile I/O scratch
     if (WLDS) {
         const char* g = reinterpret_cast<const char*>(ws);
-        for (int piece = wave; piece < 64 * FragInfo<T>::PIECES; piece += CT) glds_piece(g + piece * 1024, lds_w + piece * 1024, lane);
+        for (int piece = wave_all; piece < 64 * FragInfo<T>::PIECES; piece += CT * NG) glds_piece(g + piece * 1024, lds_w + piece * 1024, lane);
     }
     if (threadIdx.x < 64) {
         const int i = threadIdx.x * 4;
@@ -384,13 +388,17 @@ __global__ __launch_bounds__(64 * CT) void k_ang_multi(const T* __restrict__ X, 
     };
     const int view = wave * 32 + r;
     const bool ok = view < V;
-    const int vc = min(view, V - 1);
-    for (int pix = blockIdx.x; pix < npix; pix += gridDim.x) {
+    const int nrows = max(0, min(32, V - wave * 32));                // views of this column tile
+    const size_t vstride = (size_t)hw * 64 * sizeof(T);              // one view to the next, same position
+    for (int base = blockIdx.x * NG; base < npix; base += gridDim.x * NG) {
         asm volatile("" ::: "memory");
+        const bool active = base + grp < npix;                        // a trailing group repeats the last position and stores nothing
+        const int pix = min(base + grp, npix - 1);
         const int b = pix / hw, p = pix % hw;
-        const size_t off = (((size_t)b * V + vc) * hw + p) * 64;
+        const size_t off = (((size_t)b * V + min(wave * 32, V - 1)) * hw + p) * 64;   // first view of this column tile
         f32x16 x[2], n[2];
-        load_acc<2, T>(X + off, ok, hh, x);
+        if constexpr (sizeof(T) == 2) load_tile<2, T>(X + off, nrows, lane, x, scr, vstride);   // rows = views, coalesced through the scratch
+        else load_acc<2, T>(X + (((size_t)b * V + min(view, V - 1)) * hw + p) * 64, ok, hh, x);   // fp32 build: already register-bound, keep the direct form
         {
             typename RawPiece<float>::type pr[8];
             load_lane_major_raw<2, float>(pe + (size_t)wave * 2048, lane, pr);
@@ -489,6 +497,7 @@ __global__ __launch_bounds__(64 * CT) void k_ang_multi(const T* __restrict__ X, 
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) mma(wfrag(48 + nt * 8 + ks), hf[ks], x[nt]);
-        store_acc<2, T>(Y + off, ok, hh, x);
+        if constexpr (sizeof(T) == 2) store_tile<2, T>(Y + off, active ? nrows : 0, lane, x, scr, vstride);
+        else store_acc<2, T>(Y + (((size_t)b * V + min(view, V - 1)) * hw + p) * 64, ok && active, hh, x);
     }
 }
