@@ -189,13 +189,15 @@ int launch_spa1(unsigned nwg, const T* in, const T* ws, const float* ln, const T
     const size_t share = kMaxLds / LFT_SPA_OCC;                           // LDS per workgroup if LFT_SPA_OCC of them share a CU
     const bool use8 = (l16 > share && l8 <= share) || l16 > kMaxLds;
     int rc;
-    if (use8) {
-        if ((rc = allow_lds(k_spa1<T, PE_ONLY, 8>, l8, "k_spa1"))) return rc;
-        k_spa1<T, PE_ONLY, 8><<<nwg, 256, l8, st>>>(in, ws, ln, petok, tok, q, k, v, pe_out, nimg, d.h, d.w);
-    } else {
-        if ((rc = allow_lds(k_spa1<T, PE_ONLY, 16>, l16, "k_spa1"))) return rc;
-        k_spa1<T, PE_ONLY, 16><<<nwg, 256, l16, st>>>(in, ws, ln, petok, tok, q, k, v, pe_out, nimg, d.h, d.w);
-    }
+    const bool lm = !PE_ONLY && d.hw % 128 == 0;      // full tiles everywhere: hand the token tile to k_spa2 in lane-major form
+#define LFT_LAUNCH_SPA1(CHV, LMV, LDSV)                                                                                     \
+    do {                                                                                                                    \
+        if ((rc = allow_lds(k_spa1<T, PE_ONLY, CHV, LMV>, LDSV, "k_spa1"))) return rc;                                      \
+        k_spa1<T, PE_ONLY, CHV, LMV><<<nwg, 256, LDSV, st>>>(in, ws, ln, petok, tok, q, k, v, pe_out, nimg, d.h, d.w);      \
+    } while (0)
+    if (use8) { if (lm) LFT_LAUNCH_SPA1(8, true, l8); else LFT_LAUNCH_SPA1(8, false, l8); }
+    else { if (lm) LFT_LAUNCH_SPA1(16, true, l16); else LFT_LAUNCH_SPA1(16, false, l16); }
+#undef LFT_LAUNCH_SPA1
     return 0;
 }
 
@@ -352,10 +354,15 @@ int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, con
     }
     LFT_LAUNCH_OK("k_spa_attn");
     const unsigned nb = blocks_for(d.ntok, 128);
-    if ((rc = allow_lds(k_spa2<T, true>, lds_spa2<T>(), "k_spa2"))) return rc;
-    if ((rc = allow_lds(k_spa2<T, false>, lds_spa2<T>(), "k_spa2"))) return rc;
-    if (skip) k_spa2<T, true><<<nb, 256, lds_spa2<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.ntok);
-    else k_spa2<T, false><<<nb, 256, lds_spa2<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, nullptr, out, d.ntok);
+    const bool lm = d.hw % 128 == 0;                   // must match launch_spa1's choice
+#define LFT_LAUNCH_SPA2(SKV, LMV)                                                                                           \
+    do {                                                                                                                    \
+        if ((rc = allow_lds(k_spa2<T, SKV, LMV>, lds_spa2<T>(), "k_spa2"))) return rc;                                      \
+        k_spa2<T, SKV, LMV><<<nb, 256, lds_spa2<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.ntok);     \
+    } while (0)
+    if (skip) { if (lm) LFT_LAUNCH_SPA2(true, true); else LFT_LAUNCH_SPA2(true, false); }
+    else { if (lm) LFT_LAUNCH_SPA2(false, true); else LFT_LAUNCH_SPA2(false, false); }
+#undef LFT_LAUNCH_SPA2
     LFT_LAUNCH_OK("k_spa2");
     return 0;
 }

@@ -353,6 +353,48 @@ LFT_DEV void store_lane_major(T* __restrict__ tile_base, int lane, const f32x16 
             store4(tile_base + ((size_t)(nt * 2 + (g >> 1)) * 64 + lane) * 8 + (g & 1) * 4,
                    f32x4{a[nt][4 * g], a[nt][4 * g + 1], a[nt][4 * g + 2], a[nt][4 * g + 3]});
 }
+// The same layout for an ACTIVATION tile that one kernel writes and another reads with the same 32-token tiling
+// (the spatial tokens between k_spa1 and k_spa2): 16 bytes per lane and store, no LDS transposition on either side.
+// Returns the number of wave-level store instructions (for WRing::note_vm).
+template <int NT, typename T>
+LFT_DEV int store_tile_lm(T* __restrict__ tile_base, int lane, const f32x16 (&a)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            T* dst = tile_base + ((size_t)(nt * 2 + k) * 64 + lane) * 8;
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (bf16_t)a[nt][8 * k + j];
+                store_raw16(reinterpret_cast<char*>(dst), __builtin_bit_cast(raw16, v));
+            } else {
+                store_raw16(reinterpret_cast<char*>(dst), __builtin_bit_cast(raw16, f32x4{a[nt][8 * k], a[nt][8 * k + 1], a[nt][8 * k + 2], a[nt][8 * k + 3]}));
+                store_raw16(reinterpret_cast<char*>(dst + 4), __builtin_bit_cast(raw16, f32x4{a[nt][8 * k + 4], a[nt][8 * k + 5], a[nt][8 * k + 6], a[nt][8 * k + 7]}));
+            }
+        }
+    return NT * 2 * (sizeof(T) == 2 ? 1 : 2);
+}
+template <int NT, typename T>
+LFT_DEV void load_tile_lm(const T* __restrict__ tile_base, int lane, f32x16 (&a)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const T* src = tile_base + ((size_t)(nt * 2 + k) * 64 + lane) * 8;
+            if constexpr (sizeof(T) == 2) {
+                const bf16x8 v = __builtin_bit_cast(bf16x8, load_raw16(reinterpret_cast<const char*>(src)));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[nt][8 * k + j] = (float)v[j];
+            } else {
+                const f32x4 lo = __builtin_bit_cast(f32x4, load_raw16(reinterpret_cast<const char*>(src)));
+                const f32x4 hi = __builtin_bit_cast(f32x4, load_raw16(reinterpret_cast<const char*>(src + 4)));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a[nt][8 * k + j] = lo[j]; a[nt][8 * k + 4 + j] = hi[j]; }
+            }
+        }
+}
+
 template <int NT, typename T>
 LFT_DEV void load_lane_major_raw(const T* __restrict__ tile_base, int lane, typename RawPiece<T>::type (&p)[NT * 4]) {
 #pragma unroll

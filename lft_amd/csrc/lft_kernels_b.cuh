@@ -23,7 +23,7 @@ constexpr int kUpChunk = LFT_UP_CHUNK;    // k_up uses few registers: a smaller 
 #define LFT_SPA_OCC 2
 #endif
 constexpr int kSpaChunk = LFT_SPA_CHUNK;   // fragments per ring chunk: one conv tap (4 k-steps x 4 row tiles), half an in_proj matrix
-template <typename T, bool PE_ONLY, int CH = kSpaChunk>
+template <typename T, bool PE_ONLY, int CH = kSpaChunk, bool TOKLM = false>   // TOKLM: the token tile goes to k_spa2 in lane-major tile format
 __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const T* __restrict__ petok,
                                               T* __restrict__ TOK, T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vv,
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa1(const T* __restrict__
     const int t0 = p0 + wave * 32, nvalid = max(0, min(32, hw - t0));
     const size_t tile_off = ((size_t)im * hw + min(t0, hw - 1)) * 128;
     char* scr = lds_in + wave * TileIO<4, T>::BYTES;
-    ring.note_vm(store_tile<4, T>(TOK + tile_off, nvalid, lane, t, scr));
+    if constexpr (TOKLM) ring.note_vm(store_tile_lm<4, T>(TOK + ((size_t)im * hw + t0) * 128, lane, t));   // hw % 128 == 0: every tile is full
+    else ring.note_vm(store_tile<4, T>(TOK + tile_off, nvalid, lane, t, scr));
     LFT_STAMP(4);
     Frag<T> nf[8];
     // Each projection is produced and stored in two 64-channel halves: 32 accumulator registers instead of 64
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_attn_mfma(const bf16_t* __restri
 // FFN hidden width 256 is processed in four 64-wide chunks so the hidden activations never leave registers.
 // Stream: Wo[4x8, natural k] {W1c[2x8] W2c[4x4]} x4  Wl[2x8]  (176 fragments).
 // ------------------------------------------------------------------------------------------
-template <typename T, bool SKIP>
+template <typename T, bool SKIP, bool TOKLM = false>
 __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa2(const T* __restrict__ TOK, const T* __restrict__ O, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const T* __restrict__ skip, T* __restrict__ Y,
                                               long long ntok) {
@@ -565,7 +566,8 @@ __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa2(const T* __restrict__
     WRing<T, kSpaChunk> ring;
     ring.init(ws, smem, 176);                 // first: the weight DMA is in flight while the activation tiles are fetched
     f32x16 t[4], n[4];
-    load_tile<4, T>(TOK + tb * 128, nvalid, lane, t, scr);
+    if constexpr (TOKLM) load_tile_lm<4, T>(TOK + tb * 128, lane, t);       // written by k_spa1 in the same 32-token tiling
+    else load_tile<4, T>(TOK + tb * 128, nvalid, lane, t, scr);
     Frag<T> f[8];
     load_tile_frags<8, T>(O + tb * 128, nvalid, lane, f, scr);
     f32x16 sk[2];
