@@ -189,7 +189,13 @@ int launch_spa1(unsigned nwg, const T* in, const T* ws, const float* ln, const T
     const size_t share = kMaxLds / LFT_SPA_OCC;                           // LDS per workgroup if LFT_SPA_OCC of them share a CU
     const bool use8 = (l16 > share && l8 <= share) || l16 > kMaxLds;
     int rc;
-    const bool lm = !PE_ONLY && d.hw % 128 == 0;      // full tiles everywhere: hand the token tile to k_spa2 in lane-major form
+#ifndef LFT_TOKLM
+#define LFT_TOKLM 1
+#endif
+#ifndef LFT_YLM
+#define LFT_YLM 1
+#endif
+    const bool lm = LFT_TOKLM && !PE_ONLY && d.hw % 128 == 0;      // full tiles everywhere: hand the token tile to k_spa2 in lane-major form
 #define LFT_LAUNCH_SPA1(CHV, LMV, LDSV)                                                                                     \
     do {                                                                                                                    \
         if ((rc = allow_lds(k_spa1<T, PE_ONLY, CHV, LMV>, LDSV, "k_spa1"))) return rc;                                      \
@@ -335,7 +341,7 @@ int ang_block(const void* packed, const PackedLayout& L, int l, const T* in, T* 
 }
 template <typename T>
 int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, const T* skip, T* out, void* ws, const WorkLayout& W,
-              const Dims& d, hipStream_t st) {
+              const Dims& d, hipStream_t st, bool out_lm = false) {      // out_lm: lane-major output tiles, only for the up-sampler
     const int nimg = d.B * d.V, nwg = nimg * ((d.hw + 127) / 128);
     T *tok = at<T>(ws, W.tok), *q = at<T>(ws, W.q), *k = at<T>(ws, W.k), *v = at<T>(ws, W.v), *o = at<T>(ws, W.o);
     const float* ln = at<float>(packed, L.ln_spa[l]);
@@ -354,28 +360,33 @@ int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, con
     }
     LFT_LAUNCH_OK("k_spa_attn");
     const unsigned nb = blocks_for(d.ntok, 128);
-    const bool lm = d.hw % 128 == 0;                   // must match launch_spa1's choice
-#define LFT_LAUNCH_SPA2(SKV, LMV)                                                                                           \
+    const bool lm = LFT_TOKLM && d.hw % 128 == 0;      // must match launch_spa1's choice
+#define LFT_LAUNCH_SPA2(SKV, LMV, YLV)                                                                                      \
     do {                                                                                                                    \
-        if ((rc = allow_lds(k_spa2<T, SKV, LMV>, lds_spa2<T>(), "k_spa2"))) return rc;                                      \
-        k_spa2<T, SKV, LMV><<<nb, 256, lds_spa2<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.ntok);     \
+        if ((rc = allow_lds(k_spa2<T, SKV, LMV, YLV>, lds_spa2<T>(), "k_spa2"))) return rc;                                 \
+        k_spa2<T, SKV, LMV, YLV><<<nb, 256, lds_spa2<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.ntok); \
     } while (0)
-    if (skip) { if (lm) LFT_LAUNCH_SPA2(true, true); else LFT_LAUNCH_SPA2(true, false); }
-    else { if (lm) LFT_LAUNCH_SPA2(false, true); else LFT_LAUNCH_SPA2(false, false); }
+    if (out_lm && !(skip && lm)) return fail(LFT_ERR_ARG, "internal: lane-major output needs the skip variant and full tiles");
+    if (skip) { if (out_lm) LFT_LAUNCH_SPA2(true, true, true); else if (lm) LFT_LAUNCH_SPA2(true, true, false); else LFT_LAUNCH_SPA2(true, false, false); }
+    else { if (lm) LFT_LAUNCH_SPA2(false, true, false); else LFT_LAUNCH_SPA2(false, false, false); }
 #undef LFT_LAUNCH_SPA2
     LFT_LAUNCH_OK("k_spa2");
     return 0;
 }
 template <typename T>
 int upsample(const void* packed, const PackedLayout& L, const T* body, const float* lr, float* out, void* ws, const WorkLayout& W,
-             const Dims& d, hipStream_t st) {
+             const Dims& d, hipStream_t st, bool in_lm = false) {
     float* g = at<float>(ws, W.g);
     const unsigned nb = blocks_for(d.ntok, 128);
     int rc;
-    if ((rc = allow_lds(k_up<T, 1>, lds_up<T>(), "k_up"))) return rc;
-    if ((rc = allow_lds(k_up<T, 2>, lds_up<T>(), "k_up"))) return rc;
-    if (d.gt == 1) k_up<T, 1><<<nb, 256, lds_up<T>(), st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
-    else k_up<T, 2><<<nb, 256, lds_up<T>(), st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);
+#define LFT_LAUNCH_UP(GTV, LMV)                                                                                              \
+    do {                                                                                                                    \
+        if ((rc = allow_lds(k_up<T, GTV, LMV>, lds_up<T>(), "k_up"))) return rc;                                            \
+        k_up<T, GTV, LMV><<<nb, 256, lds_up<T>(), st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);            \
+    } while (0)
+    if (d.gt == 1) { if (in_lm) LFT_LAUNCH_UP(1, true); else LFT_LAUNCH_UP(1, false); }
+    else { if (in_lm) LFT_LAUNCH_UP(2, true); else LFT_LAUNCH_UP(2, false); }
+#undef LFT_LAUNCH_UP
     LFT_LAUNCH_OK("k_up");
     launch_assemble(lr, g, out, d.B, d.A, d.h, d.w, d.s, 1, st);
     LFT_LAUNCH_OK("k_assemble");
@@ -392,10 +403,11 @@ int forward_impl(const void* packed, const float* lr, float* out, void* ws, cons
     const T* cur = feat;
     for (int l = 0; l < kLayers; ++l) {                  // angular first, then spatial (reference LFT.py:249-250)
         if ((rc = ang_block<T>(packed, L, l, cur, xa, d, st))) return rc;
-        if ((rc = spa_block<T>(packed, L, l, xa, l == kLayers - 1 ? feat : nullptr, xb, ws, W, d, st))) return rc;
+        const bool last = l == kLayers - 1;                  // its output only feeds the up-sampler: same 32-token tiling, lane-major tiles
+        if ((rc = spa_block<T>(packed, L, l, xa, last ? feat : nullptr, xb, ws, W, d, st, last && LFT_TOKLM && LFT_YLM && d.hw % 128 == 0))) return rc;
         cur = xb;
     }
-    return upsample<T>(packed, L, xb, lr, out, ws, W, d, st);
+    return upsample<T>(packed, L, xb, lr, out, ws, W, d, st, LFT_TOKLM && LFT_YLM && d.hw % 128 == 0);
 }
 
 #include "lft_train_host.cuh"

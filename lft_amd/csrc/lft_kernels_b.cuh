@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_attn_mfma(const bf16_t* __restri
 // FFN hidden width 256 is processed in four 64-wide chunks so the hidden activations never leave registers.
 // Stream: Wo[4x8, natural k] {W1c[2x8] W2c[4x4]} x4  Wl[2x8]  (176 fragments).
 // ------------------------------------------------------------------------------------------
-template <typename T, bool SKIP, bool TOKLM = false>
+template <typename T, bool SKIP, bool TOKLM = false, bool YLM = false>   // YLM: output tile in lane-major form (consumer: k_up)
 __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa2(const T* __restrict__ TOK, const T* __restrict__ O, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const T* __restrict__ skip, T* __restrict__ Y,
                                               long long ntok) {
@@ -600,7 +600,8 @@ __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa2(const T* __restrict__
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) y[nt] += sk[nt];
     }
-    store_tile<2, T>(Y + tb * 64, nvalid, lane, y, scr);
+    if constexpr (YLM) store_tile_lm<2, T>(Y + tb * 64, lane, y);
+    else store_tile<2, T>(Y + tb * 64, nvalid, lane, y, scr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa2(const T* __restrict__
 // U is produced 32 rows at a time and immediately contracted into G.
 // Stream per chunk c: Wu[1x4] M[GT x 2].  G rows >= (s+2)^2 are padding.
 // ------------------------------------------------------------------------------------------
-template <typename T, int GT>
+template <typename T, int GT, bool XLM = false>   // XLM: input tile in lane-major form (producer: the last k_spa2)
 __global__ __launch_bounds__(256) void k_up(const T* __restrict__ X, const T* __restrict__ ws, float* __restrict__ G,
                                             long long ntok, int nchunk, int gp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -625,7 +626,8 @@ __global__ __launch_bounds__(256) void k_up(const T* __restrict__ X, const T* __
     WRing<T, kUpChunk> ring;
     ring.init(ws, smem, nchunk * (4 + 2 * GT));         // first: the weight DMA is in flight while the tile is fetched
     f32x16 x[2];
-    load_tile<2, T>(X + min(t0, ntok - 1) * 64, nvalid, lane, x, scr);
+    if constexpr (XLM) load_tile_lm<2, T>(X + t0 * 64, lane, x);
+    else load_tile<2, T>(X + min(t0, ntok - 1) * 64, nvalid, lane, x, scr);
     Frag<T> xf[4];
     acc_frags<2, T>(x, xf);
     f32x16 g[GT];
