@@ -150,18 +150,23 @@ struct WgP {
     int so, si, st;
     int Co, Ci, taps;
     int h, w;
-    long long N, chunk_len;           // chunk_len % 16 == 0
+    long long N, chunk_len;           // chunk_len % 64 == 0: four waves x 16-token k-steps
     int igroups;
 };
 
 // TX = 3: the wave owns a whole ROW of taps (dy fixed by blockIdx.z, dx = -1, 0, +1): the dY fragment is loaded (and
 // split) once for three products and the three shifted X rows are neighbours in memory.
+// The 4 waves of a workgroup split the chunk's tokens and add their accumulators through LDS, in a fixed order:
+// one partial image per workgroup (a quarter of the partial-sum traffic for the same number of waves in flight).
 template <int NI, bool M3, int TX>
-__global__ __launch_bounds__(64) void k_wgrad(const WgP p) {
-    const int lane = threadIdx.x, r = lane & 31, kh = lane >> 5;
+__global__ __launch_bounds__(256) void k_wgrad(const WgP p) {
+    extern __shared__ __attribute__((aligned(16))) float wred[];        // [3 waves][TX * NI tiles][16][64]
+    const int lane = threadIdx.x & 63, r = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ot = blockIdx.y / p.igroups, ig = blockIdx.y % p.igroups;
     const int o0 = ot * 32, i0 = ig * NI * 32;
-    const long long ta = (long long)blockIdx.x * p.chunk_len, tb = min(ta + p.chunk_len, p.N);
+    const long long sub = p.chunk_len >> 2;                              // chunk_len % 64 == 0
+    const long long ta = (long long)blockIdx.x * p.chunk_len + wave * sub, tb = min(ta + sub, p.N);
     const int hw = p.h * p.w;
     const int dy = TX == 3 ? (int)blockIdx.z - 1 : 0;
     f32x16 acc[TX][NI];
@@ -203,6 +208,24 @@ __global__ __launch_bounds__(64) void k_wgrad(const WgP p) {
                 for (int ni = 0; ni < NI; ++ni) mma(a, b[tx][ni], acc[tx][ni]);
         }
     }
+    if (wave) {
+#pragma unroll
+        for (int tx = 0; tx < TX; ++tx)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) wred[(((wave - 1) * TX * NI + tx * NI + ni) * 16 + i) * 64 + lane] = acc[tx][ni][i];
+    }
+    __syncthreads();
+    if (wave) return;
+#pragma unroll
+    for (int w2 = 0; w2 < 3; ++w2)
+#pragma unroll
+        for (int tx = 0; tx < TX; ++tx)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[tx][ni][i] += wred[((w2 * TX * NI + tx * NI + ni) * 16 + i) * 64 + lane];
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx) {
         const int tap = TX == 3 ? (int)blockIdx.z * 3 + tx : 0;

@@ -90,7 +90,7 @@ struct TrainLayout {
     size_t g64[5], g128[4], g256, gu, stats, dpetok, part, pgb;
     size_t part_floats, total;                   // total in floats
 };
-constexpr int kWgChunks = 512;                   // token chunks of a weight-gradient launch
+constexpr int kWgChunks = 128;                   // token chunks (= workgroups of 4 waves) of a weight-gradient launch
 constexpr int kLnBlocks = 512;                   // workgroups (= partial rows) of a LayerNorm backward
 constexpr int kTailWaves = 2048;                 // waves of the up-sampler / conv0 weight-gradient kernels
 
@@ -192,26 +192,34 @@ int lin_bwd(const TrainCtx& c, int view, const float* dY, const float* R, float*
 int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, int taps, float* dW, int accumulate, long long N) {
     if (Co % 32 || Ci % 64) return fail(LFT_ERR_ARG, "wgrad: Co %d / Ci %d not supported", Co, Ci);
     const long long wsize = (long long)Co * Ci * taps;
-    int nch = (int)std::min<long long>(kWgChunks, std::max<long long>(16, N / 128));   // >= 128 tokens per chunk: partial traffic stays below the operand traffic
+    int nch = (int)std::min<long long>(kWgChunks, std::max<long long>(4, N / 512));    // workgroups of 4 waves, >= 128 tokens per wave
     while (nch > 1 && (size_t)nch * wsize > c.T.part_floats) nch >>= 1;
     long long len = (N + nch - 1) / nch;
-    len = (len + 15) & ~15LL;
+    len = (len + 63) & ~63LL;
     WgP p{dY, Co, X, Ci, c.F(c.T.part), wsize, Ci * taps, taps, 1, Co, Ci, taps, c.d.h, c.d.w, N, len, 1};
     const bool m3 = c.math == LFT_MATH_BF16X3;
+    int rc;
+#define LFT_LAUNCH_WG(NIV, TXV, GRID)                                                                                  \
+    do {                                                                                                               \
+        const size_t lds = (size_t)3 * TXV * NIV * 16 * 64 * sizeof(float);                                            \
+        if (m3) { if ((rc = allow_lds(k_wgrad<NIV, true, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, true, TXV><<<GRID, 256, lds, c.st>>>(p); }   \
+        else { if ((rc = allow_lds(k_wgrad<NIV, false, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, false, TXV><<<GRID, 256, lds, c.st>>>(p); }    \
+    } while (0)
     if (taps == 9) {                                  // all 3x3 convolutions of the network have Ci = 64
         if (Ci != 64) return fail(LFT_ERR_ARG, "wgrad: 3x3 with Ci %d not supported", Ci);
         p.igroups = 1;
         const dim3 g((unsigned)nch, (unsigned)(Co / 32), 3u);
-        if (m3) k_wgrad<2, true, 3><<<g, 64, 0, c.st>>>(p); else k_wgrad<2, false, 3><<<g, 64, 0, c.st>>>(p);
+        LFT_LAUNCH_WG(2, 3, g);
     } else if (Ci % 128 == 0) {
         p.igroups = Ci / 128;
         const dim3 g((unsigned)nch, (unsigned)(Co / 32 * p.igroups), 1u);
-        if (m3) k_wgrad<4, true, 1><<<g, 64, 0, c.st>>>(p); else k_wgrad<4, false, 1><<<g, 64, 0, c.st>>>(p);
+        LFT_LAUNCH_WG(4, 1, g);
     } else {
         p.igroups = Ci / 64;
         const dim3 g((unsigned)nch, (unsigned)(Co / 32 * p.igroups), 1u);
-        if (m3) k_wgrad<2, true, 1><<<g, 64, 0, c.st>>>(p); else k_wgrad<2, false, 1><<<g, 64, 0, c.st>>>(p);
+        LFT_LAUNCH_WG(2, 1, g);
     }
+#undef LFT_LAUNCH_WG
     LFT_LAUNCH_OK("k_wgrad");
     k_reduce<<<blocks_for(wsize, 64), 256, 0, c.st>>>(c.F(c.T.part), nch, wsize, wsize, dW, accumulate);
     LFT_LAUNCH_OK("k_reduce");
