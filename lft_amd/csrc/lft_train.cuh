@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_lin(const LinP p) {
 // MFMA with k = token: A[m = o][k] = dY[t0 + k][o], B[k][n = i] = X[shift(t0 + k)][i]; both operands are read
 // straight from the channels-last tensors (lanes = consecutive channels of one token: 128-byte segments).
 // A wave owns one 32-row block of dY channels, one tap, NI 32-column blocks of X channels and one token chunk.
-// grid: x = chunk, y = (o tile, i group), z = tap row (3x3) or 1.   k_reduce then sums the chunks in a fixed order.
+// grid: x = chunk, y = (o tile, i group), z = tap row (3x3) or 1.   k_reduce_all then sums the chunks in a fixed order.
 // ------------------------------------------------------------------------------------------
 struct WgP {
     const float* dY; int ldy;
@@ -238,23 +238,35 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgP p) {
     }
 }
 
-// dst[i] (+)= sum_c part[c*stride + i], in a fixed order (deterministic): block = 64 elements x 4 chunk lanes.
-__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ part, int nch, long long n, long long stride, float* __restrict__ dst, int accumulate) {
+// All partial-sum reductions of one backward pass in ONE launch: every producer (weight-gradient workgroups, LayerNorm
+// backward workgroups, the two tail kernels) leaves its partials in its own region of the partial buffer, and a table of
+// segments tells this kernel what to sum where.  dst[i] = sum_c part[off + c*stride + i] (+ a second chained partial
+// set: the position-token contribution to the embedding weight).  Fixed summation order: deterministic.
+struct RedSeg { long long part_off, part2_off, dst_off; int nch, nch2, n, stride, blk0; };
+constexpr int kRedMax = 80;
+struct RedTab { int nseg, nblk; RedSeg s[kRedMax]; };
+__global__ __launch_bounds__(256) void k_reduce_all(const RedTab tab, const float* __restrict__ part, float* __restrict__ grads) {
     __shared__ float red[4][64];
+    int lo = 0, hi = tab.nseg - 1;                                      // last segment whose first block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab.s[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const RedSeg& sg = tab.s[lo];
     const int xl = threadIdx.x & 63, yl = threadIdx.x >> 6;
-    const long long i = (long long)blockIdx.x * 64 + xl;
+    const int i = ((int)blockIdx.x - sg.blk0) * 64 + xl;
     float s0 = 0.0f, s1 = 0.0f;
-    if (i < n) {
+    if (i < sg.n) {
+        const float* p1 = part + sg.part_off + i;
         int c = yl;
-        for (; c + 4 < nch; c += 8) { s0 += part[(long long)c * stride + i]; s1 += part[(long long)(c + 4) * stride + i]; }
-        if (c < nch) s0 += part[(long long)c * stride + i];
+        for (; c + 4 < sg.nch; c += 8) { s0 += p1[(long long)c * sg.stride]; s1 += p1[(long long)(c + 4) * sg.stride]; }
+        if (c < sg.nch) s0 += p1[(long long)c * sg.stride];
+        const float* p2 = part + sg.part2_off + i;
+        for (c = yl; c < sg.nch2; c += 4) s1 += p2[(long long)c * sg.stride];
     }
     red[yl][xl] = s0 + s1;
     __syncthreads();
-    if (yl == 0 && i < n) {
-        const float t = (red[0][xl] + red[1][xl]) + (red[2][xl] + red[3][xl]);
-        dst[i] = accumulate ? dst[i] + t : t;
-    }
+    if (yl == 0 && i < sg.n) grads[sg.dst_off + i] = (red[0][xl] + red[1][xl]) + (red[2][xl] + red[3][xl]);
 }
 
 // ------------------------------------------------------------------------------------------

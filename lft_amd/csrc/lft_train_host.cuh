@@ -93,6 +93,7 @@ struct TrainLayout {
 constexpr int kWgChunks = 128;                   // token chunks (= workgroups of 4 waves) of a weight-gradient launch
 constexpr int kLnBlocks = 512;                   // workgroups (= partial rows) of a LayerNorm backward
 constexpr int kTailWaves = 2048;                 // waves of the up-sampler / conv0 weight-gradient kernels
+inline int wg_chunks(long long N) { return (int)std::min<long long>(kWgChunks, std::max<long long>(4, N / 512)); }   // workgroups of 4 waves, >= 128 tokens per wave
 
 TrainLayout train_layout(const Dims& d) {
     TrainLayout T;
@@ -118,9 +119,12 @@ TrainLayout train_layout(const Dims& d) {
     for (int i = 0; i < 4; ++i) T.g128[i] = take(n * 128);
     T.g256 = take(n * 256); T.gu = take(n * 64 * ss);
     T.stats = take(n * 8 * 3); T.dpetok = take((size_t)d.hw * 128);
-    T.part_floats = std::max((size_t)kWgChunks * 128 * 576, (size_t)kTailWaves * 576);
+    // every producer of partial sums gets its own region (one k_reduce_all launch at the end of the backward pass):
+    // weight gradients (all parameters + the position-token share of the 4 embedding weights), 16 LayerNorms, 2 tails
+    T.part_floats = (size_t)wg_chunks(d.ntok) * ((size_t)param_info(d.s).total + 64) + (size_t)4 * wg_chunks(d.hw) * 128 * 576
+                    + (size_t)16 * kLnBlocks * 256 + (size_t)2 * kTailWaves * 576;
     T.part = take(T.part_floats);
-    T.pgb = take((size_t)kLnBlocks * 256);
+    T.pgb = 0;
     T.total = o;
     return T;
 }
@@ -146,6 +150,8 @@ int run_pack_split(std::vector<PackOp>& ops, float* dst, int expect_frags, hipSt
 }
 
 // ---- launch helpers ----
+struct TrainCtx;
+int red_push(const TrainCtx& c, size_t part_off, int nch, int n, int stride, float* dst, int chain);
 struct TrainCtx {
     const Dims& d;
     float* tp;                 // tape base
@@ -153,6 +159,9 @@ struct TrainCtx {
     const WViews& W;
     hipStream_t st;
     int math;                  // LFT_MATH_F32 or LFT_MATH_BF16X3
+    RedTab* red = nullptr;     // backward only: pending reductions (k_reduce_all) ...
+    size_t* part_used = nullptr;   // ... and the next free float of the partial buffer
+    const float* gbase = nullptr;  // flat gradient buffer (segment destinations are offsets into it)
     float* F(size_t off) const { return tp + off; }
 };
 
@@ -192,11 +201,13 @@ int lin_bwd(const TrainCtx& c, int view, const float* dY, const float* R, float*
 int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, int taps, float* dW, int accumulate, long long N) {
     if (Co % 32 || Ci % 64) return fail(LFT_ERR_ARG, "wgrad: Co %d / Ci %d not supported", Co, Ci);
     const long long wsize = (long long)Co * Ci * taps;
-    int nch = (int)std::min<long long>(kWgChunks, std::max<long long>(4, N / 512));    // workgroups of 4 waves, >= 128 tokens per wave
-    while (nch > 1 && (size_t)nch * wsize > c.T.part_floats) nch >>= 1;
+    const int nch = wg_chunks(N);
     long long len = (N + nch - 1) / nch;
     len = (len + 63) & ~63LL;
-    WgP p{dY, Co, X, Ci, c.F(c.T.part), wsize, Ci * taps, taps, 1, Co, Ci, taps, c.d.h, c.d.w, N, len, 1};
+    const size_t poff = *c.part_used;
+    *c.part_used += (size_t)nch * wsize;
+    if (*c.part_used > c.T.part_floats) return fail(LFT_ERR_ARG, "internal: partial buffer overflow");
+    WgP p{dY, Co, X, Ci, c.F(c.T.part) + poff, wsize, Ci * taps, taps, 1, Co, Ci, taps, c.d.h, c.d.w, N, len, 1};
     const bool m3 = c.math == LFT_MATH_BF16X3;
     int rc;
 #define LFT_LAUNCH_WG(NIV, TXV, GRID)                                                                                  \
@@ -221,8 +232,20 @@ int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, in
     }
 #undef LFT_LAUNCH_WG
     LFT_LAUNCH_OK("k_wgrad");
-    k_reduce<<<blocks_for(wsize, 64), 256, 0, c.st>>>(c.F(c.T.part), nch, wsize, wsize, dW, accumulate);
-    LFT_LAUNCH_OK("k_reduce");
+    return red_push(c, poff, nch, (int)wsize, (int)wsize, dW, accumulate);
+}
+int red_push(const TrainCtx& c, size_t part_off, int nch, int n, int stride, float* dst, int chain) {
+    RedTab& t = *c.red;
+    if (chain) {                                      // second partial set for the most recent segment with this destination
+        for (int i = t.nseg - 1; i >= 0; --i)
+            if (t.s[i].dst_off == dst - c.gbase) { t.s[i].part2_off = (long long)part_off; t.s[i].nch2 = nch; return 0; }
+        return fail(LFT_ERR_ARG, "internal: chained reduction without a first segment");
+    }
+    if (t.nseg >= kRedMax) return fail(LFT_ERR_ARG, "internal: reduction table full");
+    RedSeg& sg = t.s[t.nseg++];
+    sg.part_off = (long long)part_off; sg.part2_off = 0; sg.dst_off = dst - c.gbase;
+    sg.nch = nch; sg.nch2 = 0; sg.n = n; sg.stride = stride; sg.blk0 = t.nblk;
+    t.nblk += (n + 63) / 64;
     return 0;
 }
 int ln_fwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, const float* g, const float* b, float* Y, long long N) {
@@ -235,15 +258,16 @@ int ln_fwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, 
 int ln_bwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, const float* g, const float* dY, const float* add,
            float* out, float* dgamma, float* dbeta, long long N) {
     const int nb = (int)std::min<long long>(kLnBlocks, (N + 15) / 16);
-    if (C == 64) k_ln_bwd<64><<<nb, 256, 0, c.st>>>(X, pe, mode, g, dY, add, out, c.F(c.T.pgb), N, c.d.hw, c.d.V);
-    else k_ln_bwd<128><<<nb, 256, 0, c.st>>>(X, pe, mode, g, dY, add, out, c.F(c.T.pgb), N, c.d.hw, c.d.V);
+    const size_t poff = *c.part_used;
+    *c.part_used += (size_t)nb * 2 * C;
+    if (*c.part_used > c.T.part_floats) return fail(LFT_ERR_ARG, "internal: partial buffer overflow");
+    float* pgb = c.F(c.T.part) + poff;
+    if (C == 64) k_ln_bwd<64><<<nb, 256, 0, c.st>>>(X, pe, mode, g, dY, add, out, pgb, N, c.d.hw, c.d.V);
+    else k_ln_bwd<128><<<nb, 256, 0, c.st>>>(X, pe, mode, g, dY, add, out, pgb, N, c.d.hw, c.d.V);
     LFT_LAUNCH_OK("k_ln_bwd");
-    // pgb rows are [dgamma(C) | dbeta(C)]
-    k_reduce<<<blocks_for(C, 64), 256, 0, c.st>>>(c.F(c.T.pgb), nb, C, 2 * C, dgamma, 0);
-    LFT_LAUNCH_OK("k_reduce");
-    k_reduce<<<blocks_for(C, 64), 256, 0, c.st>>>(c.F(c.T.pgb) + C, nb, C, 2 * C, dbeta, 0);
-    LFT_LAUNCH_OK("k_reduce");
-    return 0;
+    // partial rows are [dgamma(C) | dbeta(C)] and the two gradients are neighbours in the flat buffer (norm.weight, norm.bias)
+    if (dbeta != dgamma + C) return fail(LFT_ERR_ARG, "internal: LayerNorm gradients are not adjacent");
+    return red_push(c, poff, nb, 2 * C, 2 * C, dgamma, 0);
 }
 int act_bwd(const TrainCtx& c, const float* g, const float* y, float* out, long long n, int mode) {
     k_act_bwd<<<blocks_for(n / 4, 256), 256, 0, c.st>>>(g, y, out, n / 4, mode);
@@ -347,7 +371,9 @@ int train_forward(const float* const* P, const float* lr, float* out, float* tap
 int train_backward(const float* const* P, const float* lr, float* tape, const float* dout, float* G, const Dims& d, int math, hipStream_t st) {
     const TrainLayout T = train_layout(d);
     const WViews WV = build_views(nullptr, d.s, nullptr);            // packed by this step's lft_train_forward
-    const TrainCtx c{d, tape, T, WV, st, math};
+    RedTab red{};                                                    // every partial-sum producer registers a segment here
+    size_t part_used = 0;
+    const TrainCtx c{d, tape, T, WV, st, math, &red, &part_used, G};
     const ParamInfo pi = param_info(d.s);
     const long long N = d.ntok;
     const int ss = d.s * d.s, nimg = d.B * d.V;
@@ -359,10 +385,11 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
     // ---- up-sampler tail ----
     {
         const long long nitems = N * ss, per = (nitems + kTailWaves - 1) / kTailWaves;
-        k_up_conv_bwd<<<kTailWaves / 4, 256, 0, st>>>(c.F(T.act), P[P_UP3], dout, c.F(T.gu), c.F(T.part), d.B, d.A, d.h, d.w, d.s, per);
+        const size_t poff = part_used;
+        part_used += (size_t)kTailWaves * 576;
+        k_up_conv_bwd<<<kTailWaves / 4, 256, 0, st>>>(c.F(T.act), P[P_UP3], dout, c.F(T.gu), c.F(T.part) + poff, d.B, d.A, d.h, d.w, d.s, per);
         LFT_LAUNCH_OK("k_up_conv_bwd");
-        k_reduce<<<blocks_for(576, 64), 256, 0, st>>>(c.F(T.part), kTailWaves, 576, 576, g(P_UP3), 0);
-        LFT_LAUNCH_OK("k_reduce");
+        TRY(red_push(c, poff, kTailWaves, 576, 576, g(P_UP3), 0));
         TRY(wgrad(c, c.F(T.gu), 64 * ss, c.F(T.body), 64, 1, g(P_UP0), 0, N));
         TRY(lin_bwd(c, VW_UP_B, c.F(T.gu), nullptr, gskip, N));          // d body = d y3 = d feat (global skip)
     }
@@ -431,11 +458,15 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
     TRY(lin_bwd(c, VW_CONV_B + 0, ga, gb, gb, N));                                          // d x0 = d feat + conv path
     {
         const long long per = (N + kTailWaves - 1) / kTailWaves;
-        k_conv0_wgrad<<<kTailWaves / 4, 256, 0, st>>>(gb, lr, c.F(T.part), d.B, d.A, d.h, d.w, per);
+        const size_t poff = part_used;
+        part_used += (size_t)kTailWaves * 576;
+        if (part_used > T.part_floats) return fail(LFT_ERR_ARG, "internal: partial buffer overflow");
+        k_conv0_wgrad<<<kTailWaves / 4, 256, 0, st>>>(gb, lr, c.F(T.part) + poff, d.B, d.A, d.h, d.w, per);
         LFT_LAUNCH_OK("k_conv0_wgrad");
-        k_reduce<<<blocks_for(576, 64), 256, 0, st>>>(c.F(T.part), kTailWaves, 576, 576, g(P_CONV0), 0);
-        LFT_LAUNCH_OK("k_reduce");
+        TRY(red_push(c, poff, kTailWaves, 576, 576, g(P_CONV0), 0));
     }
+    k_reduce_all<<<red.nblk, 256, 0, st>>>(red, c.F(T.part), G);      // every gradient's partial sums, one launch
+    LFT_LAUNCH_OK("k_reduce_all");
 #undef TRY
     return 0;
 }
