@@ -563,6 +563,36 @@ LFT_DEV void load_tile_frags(const T* __restrict__ gbase, int nvalid, int lane, 
     }
 }
 
+// Same with an explicit row stride: KS k-steps (16 * KS channels) out of wider rows.
+template <int KS, typename T>
+LFT_DEV void load_tile_frags_s(const T* __restrict__ gbase, size_t row_stride_bytes, int nvalid, int lane, Frag<T> (&f)[KS], char* scr) {
+    using IO = TileIO<KS / 2, T>;
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const char* g0 = reinterpret_cast<const char*>(gbase) + (size_t)pass * 16 * row_stride_bytes;
+        raw16 v[16 * IO::P16 / 64];
+#pragma unroll
+        for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
+            const int idx = i * 64 + lane, row = idx / IO::P16, pc = idx % IO::P16;
+            const bool in = pass * 16 + row < nvalid;
+            const raw16 t = load_raw16(in ? g0 + (size_t)row * row_stride_bytes + pc * 16 : reinterpret_cast<const char*>(gbase));
+            v[i] = in ? t : raw16{0u, 0u, 0u, 0u};
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
+            const int idx = i * 64 + lane;
+            store_raw16(scr + (idx / IO::P16) * IO::ROWB + (idx % IO::P16) * 16, v[i]);
+        }
+        wave_lds_fence();
+        if ((r >> 4) == pass) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) f[ks] = lds_row8(scr + (r & 15) * IO::ROWB + (16 * ks + 8 * hh) * (int)sizeof(T), true, T());
+        }
+    }
+}
+
 template <int NT>
 LFT_DEV void zero_acc(f32x16 (&a)[NT]) {
 #pragma unroll

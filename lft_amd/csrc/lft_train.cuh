@@ -83,11 +83,15 @@ struct LinP {
     long long N;
 };
 
-template <int NT, bool M3>
-__global__ __launch_bounds__(256) void k_lin(const LinP p) {
-    __shared__ __attribute__((aligned(16))) char scr_all[4 * TileIO<NT, float>::BYTES];
+// TILED (plain Linears at small batch): the 32 input rows of a wave, consecutive in memory, are fetched in coalesced
+// 64-channel chunks through the scratch instead of one 32-byte piece per lane and k-step -- fewer, fuller memory
+// requests when there are too few waves to hide latency; at large batch the direct form's higher occupancy wins.
+template <int NT, bool M3, bool TILED>
+__global__ __launch_bounds__(256, TILED ? 2 : 1) void k_lin(const LinP p) {
+    constexpr int SCR = TileIO<(NT > 2 ? NT : 2), float>::BYTES;          // output tile or a 64-channel input chunk
+    __shared__ __attribute__((aligned(16))) char scr_all[4 * SCR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, kh = lane >> 5;
-    char* scr = scr_all + wave * TileIO<NT, float>::BYTES;
+    char* scr = scr_all + wave * SCR;
     const long long t0 = ((long long)blockIdx.x * 4 + wave) * 32;
     if (t0 >= p.N) return;
     const int nvalid = (int)min((long long)32, p.N - t0);
@@ -98,6 +102,25 @@ __global__ __launch_bounds__(256) void k_lin(const LinP p) {
     f32x16 acc[NT];
     if (p.R) load_tile<NT, float>(p.R + t0 * p.ldr + o0, nvalid, lane, acc, scr, (size_t)p.ldr * 4);
     else zero_acc<NT>(acc);
+    if constexpr (TILED) {
+        // plain Linear: the wave's 32 input rows are consecutive in memory -> coalesced 64-channel chunks through the scratch
+        const int fbase = ot0 * p.KS;
+        for (int k0 = 0; k0 < p.KS; k0 += 4) {
+            Frag<float> b[4];
+            load_tile_frags_s<4, float>(p.X + t0 * p.ldx + 16 * k0, (size_t)p.ldx * 4, nvalid, lane, b, scr);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if constexpr (M3) {
+                    const Frag2 b2 = split_frag(b[ks]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mma3(load_wfrag2(p.Wp, fbase + nt * p.KS + k0 + ks, lane), b2, acc[nt]);
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mma(load_wfrag(p.Wp, fbase + nt * p.KS + k0 + ks, lane), b[ks], acc[nt]);
+                }
+            }
+        }
+    } else
     for (int tap = 0; tap < p.taps; ++tap) {
         int dy = 0, dx = 0;
         if (p.taps == 9) { dy = tap / 3 - 1; dx = tap % 3 - 1; if (p.flip) { dy = -dy; dx = -dx; } }
