@@ -87,7 +87,7 @@ struct LinP {
 // 64-channel chunks through the scratch instead of one 32-byte piece per lane and k-step -- fewer, fuller memory
 // requests when there are too few waves to hide latency; at large batch the direct form's higher occupancy wins.
 template <int NT, bool M3, bool TILED>
-__global__ __launch_bounds__(256, TILED ? 2 : 1) void k_lin(const LinP p) {
+__global__ __launch_bounds__(256, 3) void k_lin(const LinP p) {
     constexpr int SCR = TileIO<(NT > 2 ? NT : 2), float>::BYTES;          // output tile or a 64-channel input chunk
     __shared__ __attribute__((aligned(16))) char scr_all[4 * SCR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, kh = lane >> 5;
@@ -149,12 +149,13 @@ __global__ __launch_bounds__(256, TILED ? 2 : 1) void k_lin(const LinP p) {
             }
     }
     if (p.M) {                                                           // dZ = dY * act'(Z), sign(Z) read off the saved act(Z)
-        f32x16 mk[NT];
-        load_tile<NT, float>(p.M + t0 * p.ldm + o0, nvalid, lane, mk, scr, (size_t)p.ldm * 4);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {                                // one 32-channel tile at a time: 16 live registers, not 16 NT
+            f32x16 mk[1];
+            load_tile<1, float>(p.M + t0 * p.ldm + o0 + 32 * nt, nvalid, lane, mk, scr, (size_t)p.ldm * 4);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[nt][i] = mk[nt][i] > 0.0f ? acc[nt][i] : (p.mact == 1 ? 0.0f : 0.2f * acc[nt][i]);
+            for (int i = 0; i < 16; ++i) acc[nt][i] = mk[0][i] > 0.0f ? acc[nt][i] : (p.mact == 1 ? 0.0f : 0.2f * acc[nt][i]);
+        }
     }
     store_tile<NT, float>(p.Y + t0 * p.ldy + o0, nvalid, lane, acc, scr, (size_t)p.ldy * 4);
 }
