@@ -279,11 +279,12 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
     return 0;
 }
 
-void launch_assemble(const float* lr, const float* g, float* out, int B, int A, int h, int w, int s, int with_body, hipStream_t st) {
+void launch_assemble(const float* lr, const float* g, float* out, int B, int A, int h, int w, int s, int with_body, hipStream_t st, int gld = 0) {
     if (with_body) {                                    // tiled gather: 8 x 8 LR mosaic pixels per workgroup
         const dim3 tg((unsigned)((A * w + 7) / 8), (unsigned)((A * h + 7) / 8), (unsigned)B);
-        if (s == 2) k_assemble_t<2><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w);
-        else k_assemble_t<4><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w);
+        if (!gld) gld = (s + 2) * (s + 2);
+        if (s == 2) k_assemble_t<2><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w, gld);
+        else k_assemble_t<4><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w, gld);
         return;
     }
     const dim3 grid((unsigned)((A * w * s + 255) / 256), (unsigned)(A * h * s), (unsigned)B);

@@ -727,20 +727,20 @@ __global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ lr, 
 // (S+2)^2 = 36 or 16 floats).  The bicubic taps come from the LR mosaic, which is cache-resident (0.1 MB per patch).
 template <int S>
 __global__ __launch_bounds__(256) void k_assemble_t(const float* __restrict__ lr, const float* __restrict__ G, float* __restrict__ out,
-                                                    int B, int A, int h, int w) {
+                                                    int B, int A, int h, int w, int gld) {      // gld: floats between the footprints of consecutive tokens (>= GP)
     constexpr int TL = 8, HL = TL + 2, GP = (S + 2) * (S + 2), P4 = GP / 4, TS = TL * S;
     __shared__ __attribute__((aligned(16))) float gs[HL * HL * GP];
     const int MH = A * h, MW = A * w, HR_W = MW * S, HR_H = MH * S;
     const int by0 = blockIdx.y * TL, bx0 = blockIdx.x * TL, b = blockIdx.z;
     const int hw = h * w, V = A * A;
-    const float* Gb = G + (size_t)b * V * hw * GP;
+    const float* Gb = G + (size_t)b * V * hw * gld;
     for (int pidx = threadIdx.x; pidx < HL * HL * P4; pidx += 256) {
         const int slot = pidx / P4, part = pidx - slot * P4;
         const int by = by0 - 1 + slot / HL, bx = bx0 - 1 + slot % HL;
         f32x4 v = f32x4{0, 0, 0, 0};                                   // outside the mosaic: zero padding of the final conv (LFT.py:43)
         if (by >= 0 && by < MH && bx >= 0 && bx < MW) {
             const int vy = by / h, py = by - vy * h, vx = bx / w, px = bx - vx * w;
-            v = load4(Gb + ((size_t)(vy * A + vx) * hw + py * w + px) * GP + part * 4);
+            v = load4(Gb + ((size_t)(vy * A + vx) * hw + py * w + px) * gld + part * 4);
         }
         *reinterpret_cast<f32x4*>(gs + slot * GP + part * 4) = v;
     }

@@ -44,7 +44,7 @@ LFT_DEV Frag2 load_wfrag2(const float* __restrict__ stream, int f, int lane) {
     r.lo.v = __builtin_bit_cast(bf16x8, load_raw16(base + 1024));
     return r;
 }
-// k_pack's twin for the split mode: same PackOp description (kind 0, natural k order), writes hi / lo pieces.
+// k_pack's twin for the split mode: same PackOp description (natural k order), writes hi / lo pieces.
 __global__ __launch_bounds__(64) void k_pack_split(PackArgs args, float* __restrict__ dst) {
     const int f = blockIdx.x, lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     int oi = 0;
@@ -57,7 +57,8 @@ __global__ __launch_bounds__(64) void k_pack_split(PackArgs args, float* __restr
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int kk = op.k0 + 16 * ks + 8 * h + j;
-        const float v = n < op.nrows ? op.scale * op.src[(size_t)(op.row0 + n) * op.ld + kk * op.kmul + op.kadd] : 0.0f;
+        float v = 0.0f;
+        if (n < op.nrows) v = op.kind == 0 ? op.scale * op.src[(size_t)(op.row0 + n) * op.ld + kk * op.kmul + op.kadd] : upm_entry(op.src, n, kk, op.s);
         const bf16_t hi = (bf16_t)v;
         d[lane * 8 + j] = hi;
         d[512 + lane * 8 + j] = (bf16_t)(v - (float)hi);
@@ -720,8 +721,9 @@ __global__ __launch_bounds__(256, 2) void k_win_attn_lds(const float* __restrict
 
 // ------------------------------------------------------------------------------------------
 // Up-sampler tail (reference LFT.py:41-43,80): F = PixelShuffle(lrelu(U)) is never built; Aact = lrelu(U) stays
-// in token layout [N][64*s*s] (channel c*s*s + i*s + j <-> HR sub-pixel (i, j), LFT.py:41), and the mosaic-level
-// 3x3 conv 64 -> 1 reads it through the index map.  Mosaic HR pixel (Ym, Xm) <-> LR mosaic pixel (Ym/s, Xm/s) =
+// in token layout [N][64*s*s] (channel c*s*s + i*s + j <-> HR sub-pixel (i, j), LFT.py:41).  Forward: the mosaic-level
+// 3x3 conv 64 -> 1 is the overlap-add GEMM of the inference path (G = M Aact through k_lin with the packed overlap-add
+// matrix, then k_assemble_t); backward reads Aact through the index map.  Mosaic HR pixel (Ym, Xm) <-> LR mosaic pixel (Ym/s, Xm/s) =
 // (a1*h + y, a2*w + x), sub-pixel (Ym % s, Xm % s).  Zero padding only at the mosaic border.
 // ------------------------------------------------------------------------------------------
 LFT_DEV long long up_token(int b, int Ym, int Xm, int A, int h, int w, int s, int& sub) {
@@ -729,31 +731,6 @@ LFT_DEV long long up_token(int b, int Ym, int Xm, int A, int h, int w, int s, in
     sub = (Ym - ly * s) * s + (Xm - lx * s);
     const int a1 = ly / h, a2 = lx / w;
     return (((long long)b * A * A + a1 * A + a2) * h + (ly - a1 * h)) * w + (lx - a2 * w);
-}
-// out[b][Ym][Xm] = skip[..] + sum_{c, tap} w3[c][tap] * F[c][Ym + dy][Xm + dx].  One thread per HR pixel.
-__global__ __launch_bounds__(256) void k_up_conv_fwd(const float* __restrict__ Aact, const float* __restrict__ w3,
-                                                     const float* __restrict__ skip, float* __restrict__ out,
-                                                     int B, int A, int h, int w, int s) {
-    __shared__ float wl[576];
-    for (int i = threadIdx.x; i < 576; i += 256) wl[i] = w3[i];
-    __syncthreads();
-    const int HH = A * h * s, WW = A * w * s, ss = s * s;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)B * HH * WW) return;
-    const int b = (int)(idx / ((long long)HH * WW));
-    const int rem = (int)(idx % ((long long)HH * WW)), Ym = rem / WW, Xm = rem % WW;
-    float acc = skip ? skip[idx] : 0.0f;
-    for (int tap = 0; tap < 9; ++tap) {
-        const int yy = Ym + tap / 3 - 1, xx = Xm + tap % 3 - 1;
-        if (yy < 0 || yy >= HH || xx < 0 || xx >= WW) continue;
-        int sub;
-        const long long t = up_token(b, yy, xx, A, h, w, s, sub);
-        const float* row = Aact + t * 64 * ss + sub;
-        float a = 0.0f;
-        for (int c = 0; c < 64; ++c) a += wl[c * 9 + tap] * row[c * ss];
-        acc += a;
-    }
-    out[idx] = acc;
 }
 // Backward of the tail.  One wave per item = (token, sub-pixel); lane = channel c.
 //   dU[t][c*ss + sub] = lrelu'(Aact) * sum_tap w3[c][tap] * dout[Ym - dy][Xm - dx]

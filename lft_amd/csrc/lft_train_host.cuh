@@ -33,7 +33,7 @@ inline ParamInfo param_info(int s) {
 }
 
 // ---- packed weight views: every matrix the step multiplies by, in both orientations, as k_pack fragment streams ----
-enum { VW_CONV_F = 0, VW_CONV_B = 3, VW_LAYER0 = 6, VW_PER_LAYER = 24, VW_UP_F = VW_LAYER0 + 4 * VW_PER_LAYER, VW_UP_B, VW_COUNT };
+enum { VW_CONV_F = 0, VW_CONV_B = 3, VW_LAYER0 = 6, VW_PER_LAYER = 24, VW_UP_F = VW_LAYER0 + 4 * VW_PER_LAYER, VW_UP_B, VW_UPM, VW_COUNT };
 enum { MLP_F = 0, MLP_B, SIN_F, SQK_B, SUNUSED, SV_B, SOUT_F, SOUT_B, SFF1_F, SFF1_B, SFF2_F, SFF2_B, SLIN_F, SLIN_B,
        AIN_F, AQK_B, AV_B, AOUT_F, AOUT_B, AFF1_F, AFF1_B, AFF2_F, AFF2_B };
 inline int vw(int l, int which) { return VW_LAYER0 + VW_PER_LAYER * l + which; }
@@ -74,6 +74,17 @@ WViews build_views(const float* const* P, int s, std::vector<PackOp>* ops) {
         fwd(vw(l, AFF2_F), src(pidx(l, A_FF2)), 64, 128); bwd(vw(l, AFF2_B), src(pidx(l, A_FF2)), 64, 128);
     }
     fwd(VW_UP_F, src(P_UP0), 64 * s * s, 64); bwd(VW_UP_B, src(P_UP0), 64 * s * s, 64);
+    {   // overlap-add matrix of the final 3x3 conv (see k_pack / upm_entry): (s+2)^2 rows padded to 32-row tiles, 64 s^2 columns
+        const int gp = (s + 2) * (s + 2), gt = (gp + 31) / 32;
+        WView& v = W.v[VW_UPM];
+        v.frag0 = W.nfrags; v.OT = gt; v.KS = 4 * s * s; v.taps = 1;
+        W.nfrags += (size_t)gt * v.KS;
+        if (ops) {
+            PackOp m = lin_op(src(P_UP3), 0, gp, 0, 0, v.KS, 0, 1.0f);
+            m.kind = 1; m.s = s; m.ntiles = gt;
+            ops->push_back(m);
+        }
+    }
     return W;
 }
 
@@ -364,11 +375,11 @@ int train_forward(const float* const* P, const float* lr, float* out, float* tap
     }
     // ---- up-sampler + bicubic skip (LFT.py:79-81) ----
     TRY(lin_fwd(c, VW_UP_F, c.F(T.body), 2, nullptr, c.F(T.act), N));
-    launch_assemble(lr, nullptr, c.F(T.skip), d.B, d.A, d.h, d.w, d.s, 0, st);
-    LFT_LAUNCH_OK("k_assemble");
-    const long long npx = (long long)d.B * d.A * d.h * d.s * d.A * d.w * d.s;
-    k_up_conv_fwd<<<blocks_for(npx, 256), 256, 0, st>>>(c.F(T.act), P[P_UP3], c.F(T.skip), out, d.B, d.A, d.h, d.w, d.s);
-    LFT_LAUNCH_OK("k_up_conv_fwd");
+    // final 3x3 conv over the mosaic + bicubic skip: overlap-add footprints G = M lrelu(U) (backward scratch gu holds them), then gather
+    const int gt = (d.gp + 31) / 32;
+    TRY(lin_fwd(c, VW_UPM, c.F(T.act), 0, nullptr, c.F(T.gu), N, 0, gt));
+    launch_assemble(lr, c.F(T.gu), out, d.B, d.A, d.h, d.w, d.s, 1, st, 32 * gt);
+    LFT_LAUNCH_OK("k_assemble_t");
     return 0;
 }
 
