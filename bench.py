@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--scale", type=int, default=4, choices=[2, 4])
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the per-GPU batch is split over (1 = single stream)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host each step instead of replaying a HIP graph")
+    ap.add_argument("--inflight", type=int, default=2, help="steps in flight: captured forwards replayed round-robin on this many streams (1 = strictly one after the other)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -179,13 +180,18 @@ def main():
     def sync():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()                  # device-wide: covers the pipeline's streams
 
     note(f"rank {rank}/{world}: model on {dev}, precision {args.precision}, batch {args.batch}")
     step = net
+    pipe = None
     if not args.no_graph:
-        from lft_amd.module import GraphedForward
-        step = GraphedForward(net, lr)            # one HIP-graph launch per step; lr is the graph's resident input buffer
+        from lft_amd.module import GraphedForward, PipelinedForward
+        if args.inflight > 1:                     # every step: a whole batch through the whole network; consecutive steps overlap
+            pipe = PipelinedForward(net, lr, depth=args.inflight)
+            step = lambda x: pipe()               # noqa: E731  (each captured forward owns a resident copy of the input)
+        else:
+            step = GraphedForward(net, lr)        # one HIP-graph launch per step; lr is the graph's resident input buffer
     with torch.no_grad():                         # setup, before the contract's W warm-up steps: let clocks and caches settle
         for _ in range(30):
             step(lr)
@@ -238,7 +244,7 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"LFT {A}x{A} angRes {S}xSR inference, batch={args.batch} per GPU, {H}x{W} LR patches",
                        "global_batch": world * args.batch, "parallelism": f"dp{world} (independent shards)",
-                       "streams_per_gpu": args.streams, "hip_graph": not args.no_graph,
+                       "streams_per_gpu": args.streams, "hip_graph": not args.no_graph, "steps_in_flight": (args.inflight if not args.no_graph else 1),
                        "algorithmic_gflop_per_patch": flops_patch / 1e9},
             "roofline": dict(roof(dom, dom_ms), kernel=dom, **traffic_from_profile(dom, args), launch_ms=dom_ms, launches_per_forward=dom_cnt,
                              gpu_ms_per_forward=total_ms,

@@ -108,8 +108,9 @@ class get_model(nn.Module):
         return cur[1]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, lr: torch.Tensor) -> torch.Tensor:
-        """lr: float32 [B,1,A*h,A*w] on a HIP device -> float32 [B,1,A*h*s,A*w*s] (reference LFT.py:52-83)."""
+    def forward(self, lr: torch.Tensor, _slot_base: int = 0) -> torch.Tensor:
+        """lr: float32 [B,1,A*h,A*w] on a HIP device -> float32 [B,1,A*h*s,A*w*s] (reference LFT.py:52-83).
+        ``_slot_base`` selects a private set of workspaces (PipelinedForward keeps several forwards in flight)."""
         if lr.dim() != 4 or lr.size(1) != 1:
             raise ValueError(f"expected [B,1,A*h,A*w], got {tuple(lr.shape)}")
         if not lr.is_cuda:
@@ -133,7 +134,7 @@ class get_model(nn.Module):
             out = torch.empty((B, 1, H * s, W * s), dtype=torch.float32, device=x.device)
             nsplit = max(1, min(self.streams, B))
             if nsplit == 1:
-                work = self._ensure_work(x.device, B, h, w, prec)
+                work = self._ensure_work(x.device, B, h, w, prec, slot=(_slot_base, 0))
                 _lib.check(_lib.lib().lft_forward(packed.data_ptr(), x.data_ptr(), out.data_ptr(), work.data_ptr(),
                                                   B, A, h, w, s, prec, stream), "lft_forward")
             else:
@@ -147,7 +148,7 @@ class get_model(nn.Module):
                     b0, b1 = shard_range(B, i, nsplit)
                     st = side[i]
                     st.wait_event(ready)
-                    work = self._ensure_work(x.device, b1 - b0, h, w, prec, slot=i)
+                    work = self._ensure_work(x.device, b1 - b0, h, w, prec, slot=(_slot_base, i))
                     _lib.check(_lib.lib().lft_forward(packed.data_ptr(), x[b0:b1].data_ptr(), out[b0:b1].data_ptr(), work.data_ptr(),
                                                       b1 - b0, A, h, w, s, prec, st.cuda_stream), "lft_forward")
                     main.wait_stream(st)                # the caller's stream sees the finished sub-batch
@@ -159,7 +160,7 @@ class GraphedForward:
     stream fork/join become a single graph launch.  Inference only; weights must not change between replays
     (re-create after load_state_dict / optimizer steps).  Usage: g = GraphedForward(net, example_lr); out = g(lr)."""
 
-    def __init__(self, net: "get_model", example: torch.Tensor, warmup: int = 3):
+    def __init__(self, net: "get_model", example: torch.Tensor, warmup: int = 3, slot_base: int = 0):
         self.net = net
         self.static_in = example.detach().clone().contiguous()
         with torch.no_grad():
@@ -167,12 +168,12 @@ class GraphedForward:
             s.wait_stream(torch.cuda.current_stream(example.device))
             with torch.cuda.stream(s):
                 for _ in range(warmup):                # packs weights, sizes buffers, sets kernel attributes
-                    net(self.static_in)
+                    net(self.static_in, _slot_base=slot_base)
             torch.cuda.current_stream(example.device).wait_stream(s)
             torch.cuda.synchronize(example.device)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.static_out = net(self.static_in)
+                self.static_out = net(self.static_in, _slot_base=slot_base)
 
     def __call__(self, lr: torch.Tensor) -> torch.Tensor:
         if lr.shape != self.static_in.shape:
@@ -181,6 +182,40 @@ class GraphedForward:
             self.static_in.copy_(lr)
         self.graph.replay()
         return self.static_out
+
+
+class PipelinedForward:
+    """``depth`` captured forwards (own input / output / workspace buffers, shared packed weights) replayed round-robin on
+    ``depth`` HIP streams, so that consecutive steps overlap: the tail of step i (few workgroups left, CUs draining) runs
+    under the head of step i+1.  Throughput device for serving loops -- each call still processes its whole batch through
+    the whole network; only completion is asynchronous: the returned tensor is valid after ``sync()`` (or once the
+    caller's stream has waited on ``event``), and is overwritten ``depth`` calls later."""
+
+    def __init__(self, net: "get_model", example: torch.Tensor, depth: int = 2):
+        self.depth = int(depth)
+        self.graphs = [GraphedForward(net, example, slot_base=1 + k) for k in range(self.depth)]
+        self.streams = [torch.cuda.Stream(device=example.device) for _ in range(self.depth)]
+        self.events = [torch.cuda.Event() for _ in range(self.depth)]
+        self.i = 0
+        self.event = None
+
+    def __call__(self, lr: Optional[torch.Tensor] = None) -> torch.Tensor:
+        k = self.i % self.depth
+        self.i += 1
+        g, st = self.graphs[k], self.streams[k]
+        st.wait_stream(torch.cuda.current_stream(g.static_in.device))       # the caller's input is ready
+        with torch.cuda.stream(st):
+            if lr is not None and lr.data_ptr() != g.static_in.data_ptr():
+                g.static_in.copy_(lr)
+            g.graph.replay()
+            self.events[k].record(st)
+        self.event = self.events[k]
+        return g.static_out
+
+    def sync(self) -> None:
+        cur = torch.cuda.current_stream(self.graphs[0].static_in.device)
+        for st in self.streams:
+            cur.wait_stream(st)
 
 
 class get_loss(nn.Module):

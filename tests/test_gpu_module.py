@@ -126,3 +126,27 @@ def test_streams_and_graph_match_single_stream():
     torch.cuda.synchronize()
     assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])
     assert torch.equal(outs[1], outs["graph"]) and torch.equal(outs[1], outs["graph_flipped"])
+
+
+def test_pipelined_forward_matches_plain_forward():
+    """PipelinedForward (several captured forwards in flight on their own streams / buffers) returns, for every step, exactly
+    what the plain forward returns for that step's input."""
+    from lft_amd.module import PipelinedForward
+    A, s, B, h, w = 5, 4, 2, 16, 16
+    net = make_net(A, s, 1, "default", "bf16")
+    ins = [torch.from_numpy(synthetic_lr(B, A, h, w, seed=10 + i)).to("cuda:0") for i in range(5)]
+    with torch.no_grad():
+        ref = [net(x).clone() for x in ins]
+        pipe = PipelinedForward(net, ins[0], depth=2)
+        outs = []
+        for i, x in enumerate(ins):
+            y = pipe(x)
+            if i % 2 == 1 or i == len(ins) - 1:       # results stay valid for `depth` calls: collect every second call
+                pipe.sync()
+                torch.cuda.synchronize()
+                outs.append((i, y.clone()))
+                if i % 2 == 1:
+                    outs.append((i - 1, pipe.graphs[(i - 1) % 2].static_out.clone()))
+    for i, y in outs:
+        assert torch.equal(y, ref[i]), i
+    assert sorted(i for i, _ in outs) == [0, 1, 2, 3, 4]
