@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--ang", type=int, default=5, help="angular resolution (default: the BASELINE metric's 5)")
     ap.add_argument("--lr", type=int, default=32, help="LR view size (default 32)")
     ap.add_argument("--scale", type=int, default=4, choices=[2, 4])
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the per-GPU batch is split over (1 = single stream)")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams ONE step's batch is split over (1 = whole-batch kernels; overlap then comes from --inflight)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host each step instead of replaying a HIP graph")
     ap.add_argument("--inflight", type=int, default=2, help="steps in flight: captured forwards replayed round-robin on this many streams (1 = strictly one after the other)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
