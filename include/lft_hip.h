@@ -105,6 +105,9 @@ int lft_scene_integrate(const float* sr_patches, float* sr_scene, int A, int h0,
  * lft_train_backward: dout [B,1,A*h*s,A*w*s] -> grads = ONE flat fp32 buffer (lft_train_grad_floats) holding the 78
  *                     parameter gradients back to back in state_dict order, fully overwritten (not accumulated).
  *                     A data-parallel job all-reduces this one buffer.  No gradient flows to lr.
+ *                     side_stream (may be NULL): a second stream of the caller's on which the weight-gradient kernels run
+ *                     beside the data-gradient chain; it is forked from and joined back into `stream` with events, so the
+ *                     call stays stream-ordered on `stream` (and graph-capturable).
  * lft_train_tape_offset: float offset of a saved activation inside the tape, for tests ("feat", "ang0.y", "spa2.tok", ...). */
 int lft_train_tape_bytes(int B, int A, int h, int w, int s, size_t* out_bytes);
 int lft_train_grad_floats(int s, size_t* out_floats);
@@ -112,7 +115,7 @@ int lft_train_tape_offset(const char* name, int B, int A, int h, int w, int s, s
 int lft_train_forward(const float* const* params, int nparams, const float* lr, float* out, void* tape,
                       int B, int A, int h, int w, int s, int math, void* stream);
 int lft_train_backward(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
-                       int B, int A, int h, int w, int s, int math, void* stream);
+                       int B, int A, int h, int w, int s, int math, void* stream, void* side_stream);
 /* get_loss (reference LFT.py:269-277, torch.nn.L1Loss): *loss = mean |sr - hr|; if dsr != NULL also
  * dsr = gscale * sign(sr - hr) (gscale = 1/n for d loss / d sr).  scratch1024: 1024 floats of device scratch. */
 int lft_l1_loss(const float* sr, const float* hr, long long n, float* dsr, float gscale, float* loss, float* scratch1024, void* stream);

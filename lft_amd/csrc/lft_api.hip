@@ -701,14 +701,15 @@ int lft_train_forward(const float* const* params, int nparams, const float* lr, 
     return train_forward(params, lr, out, static_cast<float*>(tape), d, math, static_cast<hipStream_t>(stream));
 }
 int lft_train_backward(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
-                       int B, int A, int h, int w, int s, int math, void* stream) {
+                       int B, int A, int h, int w, int s, int math, void* stream, void* side_stream) {
     Dims d; int rc;
     if (!params || !lr || !tape || !dout || !grads) return fail(LFT_ERR_ARG, "null pointer");
     if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
     for (int i = 0; i < nparams; ++i) if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
     if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32 or LFT_MATH_BF16X3, got %d", math);
-    return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, math, static_cast<hipStream_t>(stream));
+    if (side_stream == stream) side_stream = nullptr;
+    return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, math, static_cast<hipStream_t>(stream), static_cast<hipStream_t>(side_stream));
 }
 int lft_l1_loss(const float* sr, const float* hr, long long n, float* dsr, float gscale, float* loss, float* scratch1024, void* stream) {
     if (!sr || !hr || !loss || !scratch1024 || n < 1) return fail(LFT_ERR_ARG, "bad argument");

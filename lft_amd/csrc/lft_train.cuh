@@ -439,6 +439,12 @@ __global__ void k_act_bwd(const float* g, const float* __restrict__ y, float* ou
     for (int j = 0; j < 4; ++j) o[j] = yv[j] > 0.0f ? gv[j] : (mode == 1 ? 0.0f : 0.2f * gv[j]);
     store4(out + 4 * i, o);
 }
+__global__ void k_add3(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, long long n4) {   // out = a + b
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 av = load4(a + 4 * i), bv = load4(b + 4 * i);
+    store4(out + 4 * i, f32x4{av[0] + bv[0], av[1] + bv[1], av[2] + bv[2], av[3] + bv[3]});
+}
 __global__ void k_add(float* __restrict__ a, const float* __restrict__ b, long long n4) {       // a += b
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;

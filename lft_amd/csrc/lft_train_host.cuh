@@ -98,7 +98,7 @@ struct TrainLayout {
     SpaTape spa[kLayers];
     size_t body, act, skip;                      // act = lrelu(U) [N, 64 s^2]; skip = bicubic(lr)
     // backward scratch
-    size_t g64[5], g128[4], g256, gu, stats, dpetok, part, pgb;
+    size_t bwd, bwd_floats, gu, stats, part, pgb;       // bwd: gradient tensors of the backward pass, one fresh buffer each
     size_t part_floats, total;                   // total in floats
 };
 constexpr int kWgChunks = 128;                   // token chunks (= workgroups of 4 waves) of a weight-gradient launch
@@ -126,10 +126,13 @@ TrainLayout train_layout(const Dims& d) {
     }
     T.body = take(n * 64); T.act = take(n * 64 * ss);
     T.skip = take((size_t)d.B * d.A * d.h * d.s * d.A * d.w * d.s);
-    for (int i = 0; i < 5; ++i) T.g64[i] = take(n * 64);
-    for (int i = 0; i < 4; ++i) T.g128[i] = take(n * 128);
-    T.g256 = take(n * 256); T.gu = take(n * 64 * ss);
-    T.stats = take(n * 8 * 3); T.dpetok = take((size_t)d.hw * 128);
+    // Every gradient tensor of the backward pass gets its own buffer (no reuse): the weight-gradient kernels then only
+    // depend on their producers and can run on a second stream beside the data-gradient chain.  Per token: the tail 64,
+    // per layer 1728 (SpaTrans) + 704 (AngTrans), the feature extractor 320 floats; plus the 4 position-token gradients.
+    T.bwd_floats = n * (64 + (size_t)kLayers * (1728 + 704) + 320) + (size_t)kLayers * (((size_t)d.hw * 128 + 63) & ~(size_t)63);
+    T.bwd = take(T.bwd_floats);
+    T.gu = take(n * 64 * ss);
+    T.stats = take(n * 8 * 3);
     // every producer of partial sums gets its own region (one k_reduce_all launch at the end of the backward pass):
     // weight gradients (all parameters + the position-token share of the 4 embedding weights), 16 LayerNorms, 2 tails
     T.part_floats = (size_t)wg_chunks(d.ntok) * ((size_t)param_info(d.s).total + 64) + (size_t)4 * wg_chunks(d.hw) * 128 * 576
@@ -173,6 +176,7 @@ struct TrainCtx {
     RedTab* red = nullptr;     // backward only: pending reductions (k_reduce_all) ...
     size_t* part_used = nullptr;   // ... and the next free float of the partial buffer
     const float* gbase = nullptr;  // flat gradient buffer (segment destinations are offsets into it)
+    hipStream_t side = nullptr;    // backward only: stream of the weight-gradient kernels (null: same stream)
     float* F(size_t off) const { return tp + off; }
 };
 
@@ -213,6 +217,20 @@ int lin_bwd(const TrainCtx& c, int view, const float* dY, const float* R, float*
     const WView& v = c.W.v[view];
     return run_lin(c, view, 0, 0, dY, v.KS * 16, 1, 0, R, v.OT * 32, dX, v.OT * 32, N, M, mact);
 }
+// Events ordering the side stream after the producers on the main stream (host objects, created once per thread and reused;
+// a re-record only affects waits enqueued after it).
+hipEvent_t next_event() {
+    static thread_local std::vector<hipEvent_t> pool;
+    static thread_local size_t cursor = 0;
+    if (cursor >= pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        pool.push_back(e);
+    }
+    hipEvent_t e = pool[cursor];
+    cursor = (cursor + 1) % 256;                       // far more than one backward pass records
+    return e;
+}
 // weight gradient of either: dW (+)= dY^T X  (taps = 1 or 9)
 int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, int taps, float* dW, int accumulate, long long N) {
     if (Co % 32 || Ci % 64) return fail(LFT_ERR_ARG, "wgrad: Co %d / Ci %d not supported", Co, Ci);
@@ -223,14 +241,22 @@ int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, in
     const size_t poff = *c.part_used;
     *c.part_used += (size_t)nch * wsize;
     if (*c.part_used > c.T.part_floats) return fail(LFT_ERR_ARG, "internal: partial buffer overflow");
+    hipStream_t ws = c.st;
+    if (c.side) {                                      // dY was produced by the last kernel enqueued on the main stream
+        hipEvent_t ev = next_event();
+        if (!ev) return fail(LFT_ERR_ARG, "hipEventCreate failed");
+        LFT_HIP_OK(hipEventRecord(ev, c.st));
+        LFT_HIP_OK(hipStreamWaitEvent(c.side, ev, 0));
+        ws = c.side;
+    }
     WgP p{dY, Co, X, Ci, c.F(c.T.part) + poff, wsize, Ci * taps, taps, 1, Co, Ci, taps, c.d.h, c.d.w, N, len, 1};
     const bool m3 = c.math == LFT_MATH_BF16X3;
     int rc;
 #define LFT_LAUNCH_WG(NIV, TXV, GRID)                                                                                  \
     do {                                                                                                               \
         const size_t lds = (size_t)3 * TXV * NIV * 16 * 64 * sizeof(float);                                            \
-        if (m3) { if ((rc = allow_lds(k_wgrad<NIV, true, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, true, TXV><<<GRID, 256, lds, c.st>>>(p); }   \
-        else { if ((rc = allow_lds(k_wgrad<NIV, false, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, false, TXV><<<GRID, 256, lds, c.st>>>(p); }    \
+        if (m3) { if ((rc = allow_lds(k_wgrad<NIV, true, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, true, TXV><<<GRID, 256, lds, ws>>>(p); }   \
+        else { if ((rc = allow_lds(k_wgrad<NIV, false, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, false, TXV><<<GRID, 256, lds, ws>>>(p); }    \
     } while (0)
     if (taps == 9) {                                  // all 3x3 convolutions of the network have Ci = 64
         if (Ci != 64) return fail(LFT_ERR_ARG, "wgrad: 3x3 with Ci %d not supported", Ci);
@@ -288,6 +314,11 @@ int ln_bwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, 
 int act_bwd(const TrainCtx& c, const float* g, const float* y, float* out, long long n, int mode) {
     k_act_bwd<<<blocks_for(n / 4, 256), 256, 0, c.st>>>(g, y, out, n / 4, mode);
     LFT_LAUNCH_OK("k_act_bwd");
+    return 0;
+}
+int add3(const TrainCtx& c, float* out, const float* a, const float* b, long long n) {
+    k_add3<<<blocks_for(n / 4, 256), 256, 0, c.st>>>(out, a, b, n / 4);
+    LFT_LAUNCH_OK("k_add3");
     return 0;
 }
 int add_to(const TrainCtx& c, float* a, const float* b, long long n) {
@@ -384,102 +415,137 @@ int train_forward(const float* const* P, const float* lr, float* out, float* tap
 }
 
 // ---------------------------------------------------------------------------- backward
-int train_backward(const float* const* P, const float* lr, float* tape, const float* dout, float* G, const Dims& d, int math, hipStream_t st) {
+int train_backward(const float* const* P, const float* lr, float* tape, const float* dout, float* G, const Dims& d, int math,
+                   hipStream_t st, hipStream_t side) {
     const TrainLayout T = train_layout(d);
     const WViews WV = build_views(nullptr, d.s, nullptr);            // packed by this step's lft_train_forward
     RedTab red{};                                                    // every partial-sum producer registers a segment here
     size_t part_used = 0;
-    const TrainCtx c{d, tape, T, WV, st, math, &red, &part_used, G};
+    const TrainCtx c{d, tape, T, WV, st, math, &red, &part_used, G, side};
     const ParamInfo pi = param_info(d.s);
     const long long N = d.ntok;
     const int ss = d.s * d.s, nimg = d.B * d.V;
     int rc;
     auto g = [&](int idx) { return G + pi.off[idx]; };
-    float *gskip = c.F(T.g64[0]), *ga = c.F(T.g64[1]), *gb = c.F(T.g64[2]), *t64a = c.F(T.g64[3]), *t64b = c.F(T.g64[4]);
-    float *h0 = c.F(T.g128[0]), *h1 = c.F(T.g128[1]), *h2 = c.F(T.g128[2]), *h4 = c.F(T.g128[3]);
-    float* g256 = c.F(T.g256);
+    size_t soff = 0;
+    auto nb = [&](int width) { float* p = c.F(T.bwd) + soff; soff += (size_t)N * width; return p; };   // fresh [N][width] gradient buffer
     // ---- up-sampler tail ----
+    float* gu = c.F(T.gu);
     {
         const long long nitems = N * ss, per = (nitems + kTailWaves - 1) / kTailWaves;
         const size_t poff = part_used;
         part_used += (size_t)kTailWaves * 576;
-        k_up_conv_bwd<<<kTailWaves / 4, 256, 0, st>>>(c.F(T.act), P[P_UP3], dout, c.F(T.gu), c.F(T.part) + poff, d.B, d.A, d.h, d.w, d.s, per);
+        k_up_conv_bwd<<<kTailWaves / 4, 256, 0, st>>>(c.F(T.act), P[P_UP3], dout, gu, c.F(T.part) + poff, d.B, d.A, d.h, d.w, d.s, per);
         LFT_LAUNCH_OK("k_up_conv_bwd");
         TRY(red_push(c, poff, kTailWaves, 576, 576, g(P_UP3), 0));
-        TRY(wgrad(c, c.F(T.gu), 64 * ss, c.F(T.body), 64, 1, g(P_UP0), 0, N));
-        TRY(lin_bwd(c, VW_UP_B, c.F(T.gu), nullptr, gskip, N));          // d body = d y3 = d feat (global skip)
     }
+    TRY(wgrad(c, gu, 64 * ss, c.F(T.body), 64, 1, g(P_UP0), 0, N));
+    float* gskip = nb(64);
+    TRY(lin_bwd(c, VW_UP_B, gu, nullptr, gskip, N));                 // d body = d y3 = d feat (global skip)
     const float* dy = gskip;
     for (int l = kLayers - 1; l >= 0; --l) {
-        // ================= SpaTrans backward: dy [N,64] -> dx in ga =================
+        // ================= SpaTrans backward: dy [N,64] -> dx =================
+        float* dx;
         {
             const SpaTape& sp = T.spa[l];
             const float* xin = c.F(T.ang[l].y);
             float* gin = g(pidx(l, S_INPROJ));
             TRY(wgrad(c, dy, 64, c.F(sp.t2), 128, 1, g(pidx(l, S_LIN)), 0, N));
-            TRY(lin_bwd(c, vw(l, SLIN_B), dy, nullptr, h0, N));                         // d t2
-            TRY(wgrad(c, h0, 128, c.F(sp.hdn), 256, 1, g(pidx(l, S_FF2)), 0, N));
-            TRY(lin_bwd(c, vw(l, SFF2_B), h0, nullptr, g256, N, c.F(sp.hdn), 1));      // d (W1 m) = d hdn * relu'()
-            TRY(wgrad(c, g256, 256, c.F(sp.m), 128, 1, g(pidx(l, S_FF1)), 0, N));
-            TRY(lin_bwd(c, vw(l, SFF1_B), g256, nullptr, h1, N));                      // d m
-            TRY(ln_bwd(c, 128, c.F(sp.t1), nullptr, 0, P[pidx(l, S_N2W)], h1, h0, h0, g(pidx(l, S_N2W)), g(pidx(l, S_N2B)), N));   // h0 = d t1
-            TRY(wgrad(c, h0, 128, c.F(sp.o), 128, 1, g(pidx(l, S_OUT)), 0, N));
-            TRY(lin_bwd(c, vw(l, SOUT_B), h0, nullptr, h1, N));                        // h1 = d O
-            TRY(win_attn<1>(c, c.F(sp.qk), c.F(sp.qk) + 128, c.F(sp.v), nullptr, h1, g256, nullptr, nullptr));        // g256 = [dQ | . ] (+ row stats)
-            TRY(win_attn<2>(c, c.F(sp.qk), c.F(sp.qk) + 128, c.F(sp.v), nullptr, h1, nullptr, g256 + 128, h4));      // g256 = [dQ | dK], h4 = dV
-            TRY(wgrad(c, h4, 128, c.F(sp.tok), 128, 1, gin + 256 * 128, 0, N));
-            TRY(lin_bwd(c, vw(l, SV_B), h4, h0, h0, N));                               // d tok += dV Wv
-            TRY(wgrad(c, g256, 256, c.F(sp.n), 128, 1, gin, 0, N));                    // rows 0..255 of in_proj: Wq, Wk
-            TRY(lin_bwd(c, vw(l, SQK_B), g256, nullptr, h1, N));                       // h1 = d n
-            TRY(ln_bwd(c, 128, c.F(sp.tok), c.F(sp.petok), 2, P[pidx(l, S_N1W)], h1, nullptr, h2, g(pidx(l, S_N1W)), g(pidx(l, S_N1B)), N));  // h2 = d(tok+pe)
-            k_sum_images<<<blocks_for((long long)d.hw * 128, 256), 256, 0, st>>>(h2, nimg, (long long)d.hw * 128, c.F(T.dpetok));
+            float* dt2 = nb(128);
+            TRY(lin_bwd(c, vw(l, SLIN_B), dy, nullptr, dt2, N));
+            TRY(wgrad(c, dt2, 128, c.F(sp.hdn), 256, 1, g(pidx(l, S_FF2)), 0, N));
+            float* dhz = nb(256);
+            TRY(lin_bwd(c, vw(l, SFF2_B), dt2, nullptr, dhz, N, c.F(sp.hdn), 1));           // d (W1 m) = d hdn * relu'()
+            TRY(wgrad(c, dhz, 256, c.F(sp.m), 128, 1, g(pidx(l, S_FF1)), 0, N));
+            float* dm = nb(128);
+            TRY(lin_bwd(c, vw(l, SFF1_B), dhz, nullptr, dm, N));
+            float* dt1 = nb(128);
+            TRY(ln_bwd(c, 128, c.F(sp.t1), nullptr, 0, P[pidx(l, S_N2W)], dm, dt2, dt1, g(pidx(l, S_N2W)), g(pidx(l, S_N2B)), N));
+            TRY(wgrad(c, dt1, 128, c.F(sp.o), 128, 1, g(pidx(l, S_OUT)), 0, N));
+            float* dO = nb(128);
+            TRY(lin_bwd(c, vw(l, SOUT_B), dt1, nullptr, dO, N));
+            float* dqk = nb(256);
+            float* dV = nb(128);
+            TRY(win_attn<1>(c, c.F(sp.qk), c.F(sp.qk) + 128, c.F(sp.v), nullptr, dO, dqk, nullptr, nullptr));        // dQ (+ row stats)
+            TRY(win_attn<2>(c, c.F(sp.qk), c.F(sp.qk) + 128, c.F(sp.v), nullptr, dO, nullptr, dqk + 128, dV));      // dK, dV
+            TRY(wgrad(c, dV, 128, c.F(sp.tok), 128, 1, gin + 256 * 128, 0, N));
+            float* dtokA = nb(128);
+            TRY(lin_bwd(c, vw(l, SV_B), dV, dt1, dtokA, N));                                 // d tok = d t1 + dV Wv ...
+            TRY(wgrad(c, dqk, 256, c.F(sp.n), 128, 1, gin, 0, N));                           // rows 0..255 of in_proj: Wq, Wk
+            float* dn = nb(128);
+            TRY(lin_bwd(c, vw(l, SQK_B), dqk, nullptr, dn, N));
+            float* du = nb(128);
+            TRY(ln_bwd(c, 128, c.F(sp.tok), c.F(sp.petok), 2, P[pidx(l, S_N1W)], dn, nullptr, du, g(pidx(l, S_N1W)), g(pidx(l, S_N1B)), N));  // d(tok+pe)
+            float* dpe = c.F(T.bwd) + soff;
+            soff += ((size_t)d.hw * 128 + 63) & ~(size_t)63;
+            k_sum_images<<<blocks_for((long long)d.hw * 128, 256), 256, 0, st>>>(du, nimg, (long long)d.hw * 128, dpe);
             LFT_LAUNCH_OK("k_sum_images");
-            TRY(add_to(c, h0, h2, N * 128));                                                         // h0 = d tok (total)
-            TRY(wgrad(c, h0, 128, xin, 64, 9, g(pidx(l, S_MLP)), 0, N));
-            {   // the position tokens are MLP(unfold(PE)) too (LFT.py:180): one more image of N = hw tokens
-                TRY(wgrad(c, c.F(T.dpetok), 128, c.F(T.pe_spa), 64, 9, g(pidx(l, S_MLP)), 1, d.hw));
-            }
-            TRY(lin_bwd(c, vw(l, MLP_B), h0, nullptr, ga, N));                        // ga = d x_in
+            float* dtok = nb(128);
+            TRY(add3(c, dtok, dtokA, du, N * 128));                                          // ... + d(tok+pe)
+            TRY(wgrad(c, dtok, 128, xin, 64, 9, g(pidx(l, S_MLP)), 0, N));
+            TRY(wgrad(c, dpe, 128, c.F(T.pe_spa), 64, 9, g(pidx(l, S_MLP)), 1, d.hw));      // the position tokens are MLP(unfold(PE)) too (LFT.py:180)
+            dx = nb(64);
+            TRY(lin_bwd(c, vw(l, MLP_B), dtok, nullptr, dx, N));
         }
-        // ================= AngTrans backward: ga -> gb =================
+        // ================= AngTrans backward: dx -> dy of the layer below =================
         {
             const AngTape& a = T.ang[l];
             const float* xin = l == 0 ? c.F(T.feat) : c.F(T.spa[l - 1].y);
             float* gin = g(pidx(l, A_INPROJ));
-            TRY(wgrad(c, ga, 64, c.F(a.hdn), 128, 1, g(pidx(l, A_FF2)), 0, N));
-            TRY(lin_bwd(c, vw(l, AFF2_B), ga, nullptr, h0, N, c.F(a.hdn), 1));         // d (W1 m) = d hdn * relu'()
-            TRY(wgrad(c, h0, 128, c.F(a.m), 64, 1, g(pidx(l, A_FF1)), 0, N));
-            TRY(lin_bwd(c, vw(l, AFF1_B), h0, nullptr, t64a, N));                       // d m
-            TRY(ln_bwd(c, 64, c.F(a.t1), nullptr, 0, P[pidx(l, A_N2W)], t64a, ga, gb, g(pidx(l, A_N2W)), g(pidx(l, A_N2B)), N));   // gb = d t1
-            TRY(wgrad(c, gb, 64, c.F(a.o), 64, 1, g(pidx(l, A_OUT)), 0, N));
-            TRY(lin_bwd(c, vw(l, AOUT_B), gb, nullptr, t64a, N));                        // d o
-            TRY(ang_attn<true>(c, c.F(a.qk), c.F(a.v), nullptr, t64a, h0, t64b));                    // h0 = dQK, t64b = dV
-            TRY(wgrad(c, t64b, 64, xin, 64, 1, gin + 128 * 64, 0, N));
-            TRY(lin_bwd(c, vw(l, AV_B), t64b, gb, gb, N));                                // d x += dV Wv
-            TRY(wgrad(c, h0, 128, c.F(a.n), 64, 1, gin, 0, N));
-            TRY(lin_bwd(c, vw(l, AQK_B), h0, nullptr, t64a, N));                                     // d n
-            TRY(ln_bwd(c, 64, xin, c.F(T.pe_ang), 1, P[pidx(l, A_N1W)], t64a, gb, gb, g(pidx(l, A_N1W)), g(pidx(l, A_N1B)), N));
+            TRY(wgrad(c, dx, 64, c.F(a.hdn), 128, 1, g(pidx(l, A_FF2)), 0, N));
+            float* dhz = nb(128);
+            TRY(lin_bwd(c, vw(l, AFF2_B), dx, nullptr, dhz, N, c.F(a.hdn), 1));             // d (W1 m) = d hdn * relu'()
+            TRY(wgrad(c, dhz, 128, c.F(a.m), 64, 1, g(pidx(l, A_FF1)), 0, N));
+            float* dm = nb(64);
+            TRY(lin_bwd(c, vw(l, AFF1_B), dhz, nullptr, dm, N));
+            float* dt1 = nb(64);
+            TRY(ln_bwd(c, 64, c.F(a.t1), nullptr, 0, P[pidx(l, A_N2W)], dm, dx, dt1, g(pidx(l, A_N2W)), g(pidx(l, A_N2B)), N));
+            TRY(wgrad(c, dt1, 64, c.F(a.o), 64, 1, g(pidx(l, A_OUT)), 0, N));
+            float* dO = nb(64);
+            TRY(lin_bwd(c, vw(l, AOUT_B), dt1, nullptr, dO, N));
+            float* dqk = nb(128);
+            float* dV = nb(64);
+            TRY(ang_attn<true>(c, c.F(a.qk), c.F(a.v), nullptr, dO, dqk, dV));
+            TRY(wgrad(c, dV, 64, xin, 64, 1, gin + 128 * 64, 0, N));
+            float* dxa = nb(64);
+            TRY(lin_bwd(c, vw(l, AV_B), dV, dt1, dxa, N));                                   // d x = d t1 + dV Wv ...
+            TRY(wgrad(c, dqk, 128, c.F(a.n), 64, 1, gin, 0, N));
+            float* dn = nb(64);
+            TRY(lin_bwd(c, vw(l, AQK_B), dqk, nullptr, dn, N));
+            float* dxo = nb(64);
+            TRY(ln_bwd(c, 64, xin, c.F(T.pe_ang), 1, P[pidx(l, A_N1W)], dn, dxa, dxo, g(pidx(l, A_N1W)), g(pidx(l, A_N1B)), N));   // ... + d LN(x + PE)
+            dy = dxo;
         }
-        dy = gb;
-        // next iteration's SpaTrans writes ga, AngTrans writes gb while reading ga: dy = gb is only read by the SpaTrans part
     }
-    // ---- initial feature extractor: d feat = gb + gskip ----
-    TRY(add_to(c, gb, gskip, N * 64));
-    TRY(act_bwd(c, gb, c.F(T.c3), ga, N * 64, 2));                                                   // d z3
-    TRY(wgrad(c, ga, 64, c.F(T.c2), 64, 9, g(P_CONV + 2), 0, N));
-    TRY(lin_bwd(c, VW_CONV_B + 2, ga, nullptr, gskip, N, c.F(T.c2), 2));                    // d z2 = d c2 * lrelu'()
-    TRY(wgrad(c, gskip, 64, c.F(T.c1), 64, 9, g(P_CONV + 1), 0, N));
-    TRY(lin_bwd(c, VW_CONV_B + 1, gskip, nullptr, ga, N, c.F(T.c1), 2));                    // d z1 = d c1 * lrelu'()
-    TRY(wgrad(c, ga, 64, c.F(T.x0), 64, 9, g(P_CONV + 0), 0, N));
-    TRY(lin_bwd(c, VW_CONV_B + 0, ga, gb, gb, N));                                          // d x0 = d feat + conv path
+    // ---- initial feature extractor ----
+    float* dfeat = nb(64);
+    TRY(add3(c, dfeat, dy, gskip, N * 64));
+    float* dz3 = nb(64);
+    TRY(act_bwd(c, dfeat, c.F(T.c3), dz3, N * 64, 2));
+    TRY(wgrad(c, dz3, 64, c.F(T.c2), 64, 9, g(P_CONV + 2), 0, N));
+    float* dz2 = nb(64);
+    TRY(lin_bwd(c, VW_CONV_B + 2, dz3, nullptr, dz2, N, c.F(T.c2), 2));                    // d z2 = d c2 * lrelu'()
+    TRY(wgrad(c, dz2, 64, c.F(T.c1), 64, 9, g(P_CONV + 1), 0, N));
+    float* dz1 = nb(64);
+    TRY(lin_bwd(c, VW_CONV_B + 1, dz2, nullptr, dz1, N, c.F(T.c1), 2));                    // d z1 = d c1 * lrelu'()
+    TRY(wgrad(c, dz1, 64, c.F(T.x0), 64, 9, g(P_CONV + 0), 0, N));
+    float* dx0 = nb(64);
+    TRY(lin_bwd(c, VW_CONV_B + 0, dz1, dfeat, dx0, N));                                    // d x0 = d feat + conv path
+    if (soff > T.bwd_floats) return fail(LFT_ERR_ARG, "internal: backward scratch overflow (%zu > %zu)", soff, T.bwd_floats);
     {
         const long long per = (N + kTailWaves - 1) / kTailWaves;
         const size_t poff = part_used;
         part_used += (size_t)kTailWaves * 576;
         if (part_used > T.part_floats) return fail(LFT_ERR_ARG, "internal: partial buffer overflow");
-        k_conv0_wgrad<<<kTailWaves / 4, 256, 0, st>>>(gb, lr, c.F(T.part) + poff, d.B, d.A, d.h, d.w, per);
+        k_conv0_wgrad<<<kTailWaves / 4, 256, 0, st>>>(dx0, lr, c.F(T.part) + poff, d.B, d.A, d.h, d.w, per);
         LFT_LAUNCH_OK("k_conv0_wgrad");
         TRY(red_push(c, poff, kTailWaves, 576, 576, g(P_CONV0), 0));
+    }
+    if (side) {                                                      // the weight-gradient stream joins before the reduction
+        hipEvent_t ev = next_event();
+        if (!ev) return fail(LFT_ERR_ARG, "hipEventCreate failed");
+        LFT_HIP_OK(hipEventRecord(ev, side));
+        LFT_HIP_OK(hipStreamWaitEvent(st, ev, 0));
     }
     k_reduce_all<<<red.nblk, 256, 0, st>>>(red, c.F(T.part), G);      // every gradient's partial sums, one launch
     LFT_LAUNCH_OK("k_reduce_all");

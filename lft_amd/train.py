@@ -72,7 +72,18 @@ def train_forward(ps, lr, A, s, tape=None, math="fp32"):
     return out, tape
 
 
-def train_backward(ps, lr, tape, dout, A, s, grads=None, math="fp32"):
+_side_streams = {}
+
+
+def side_stream(dev) -> torch.cuda.Stream:
+    """The per-device stream on which the weight-gradient kernels of a backward pass run beside the main chain."""
+    key = str(dev)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
+
+
+def train_backward(ps, lr, tape, dout, A, s, grads=None, math="fp32", overlap=True):
     """lft_train_backward: returns the flat gradient buffer (78 gradients back to back, state_dict order)."""
     B, _, H, W = lr.shape
     h, w = H // A, W // A
@@ -81,7 +92,8 @@ def train_backward(ps, lr, tape, dout, A, s, grads=None, math="fp32"):
         grads = torch.empty(grad_floats(s), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     _lib.check(_lib.lib().lft_train_backward(_ptr_array(ps), len(ps), lr.data_ptr(), tape.data_ptr(), dout.data_ptr(), grads.data_ptr(),
-                                             B, A, h, w, s, MATH[math], stream), "lft_train_backward")
+                                             B, A, h, w, s, MATH[math], stream, side_stream(dev).cuda_stream if overlap else None),
+               "lft_train_backward")
     return grads
 
 

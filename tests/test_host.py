@@ -92,7 +92,7 @@ def test_training_and_metrics_size_queries_and_argument_errors():
     assert b"78" in L.lft_last_error()
     assert L.lft_train_forward(arr, 78, 1, 1, 1, 1, 5, 8, 8, 2, 9, None) == -1
     assert b"math" in L.lft_last_error()
-    assert L.lft_train_backward(arr, 78, 1, 1, None, 1, 1, 5, 8, 8, 2, 0, None) == -1    # null dout
+    assert L.lft_train_backward(arr, 78, 1, 1, None, 1, 1, 5, 8, 8, 2, 0, None, None) == -1    # null dout
     assert L.lft_view_metrics_scratch_bytes(1, 5, 32, 32, ctypes.byref(n)) == 0 and n.value == 25 * 4 * 3 * 8
     assert L.lft_view_metrics(1, 1, 1, 5, 8, 8, 2.0, 1, 1, 1, None) == -2                 # views smaller than the SSIM window
     assert L.lft_adam_step(1, 1, 1, 1, 10, 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, None) == -1   # steps count from 1
