@@ -7,7 +7,7 @@
 // them.  One PackOp describes ntiles x ksteps fragments (nt-major) cut from a row-major fp32 matrix:
 //   frag(nt, ks)[lane = 32h + r][j] = scale * src[(row0 + 32 nt + r) * ld + (k0 + 16 ks + kk(h, j)) * kmul + kadd]
 // kmap 0: natural kk = 8h + j (operand loaded from memory); kmap 1: acc order (see lft_common.cuh).
-// kind 1 (UPM) builds the "overlap-add" matrix of the final 3x3 convolution instead (see k_up).
+// kind 1 (UPM) builds the "overlap-add" matrix of the final 3x3 convolution instead (see k_up); kind 2 its transpose.
 // ------------------------------------------------------------------------------------------
 struct PackOp {
     const float* src;
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(64) void k_pack(PackArgs args, T* __restrict__ dst)
         float v = 0.0f;
         if (n < op.nrows) {
             if (op.kind == 0) v = op.scale * op.src[(size_t)(op.row0 + n) * op.ld + kk * op.kmul + op.kadd];
-            else v = upm_entry(op.src, n, kk, op.s);
+            else if (op.kind == 1) v = upm_entry(op.src, n, kk, op.s);
+            else v = kk < (op.s + 2) * (op.s + 2) ? upm_entry(op.src, kk, n, op.s) : 0.0f;   // kind 2: the transposed matrix (rows = PixelShuffle channels)
         }
         if constexpr (sizeof(T) == 4) dst[(((size_t)f * 2 + (j >> 2)) * 64 + lane) * 4 + (j & 3)] = (T)v;   // two 1 KiB pieces
         else dst[((size_t)f * 64 + lane) * 8 + j] = (T)v;

@@ -58,7 +58,11 @@ __global__ __launch_bounds__(64) void k_pack_split(PackArgs args, float* __restr
     for (int j = 0; j < 8; ++j) {
         const int kk = op.k0 + 16 * ks + 8 * h + j;
         float v = 0.0f;
-        if (n < op.nrows) v = op.kind == 0 ? op.scale * op.src[(size_t)(op.row0 + n) * op.ld + kk * op.kmul + op.kadd] : upm_entry(op.src, n, kk, op.s);
+        if (n < op.nrows) {
+            if (op.kind == 0) v = op.scale * op.src[(size_t)(op.row0 + n) * op.ld + kk * op.kmul + op.kadd];
+            else if (op.kind == 1) v = upm_entry(op.src, n, kk, op.s);
+            else v = kk < (op.s + 2) * (op.s + 2) ? upm_entry(op.src, kk, n, op.s) : 0.0f;
+        }
         const bf16_t hi = (bf16_t)v;
         d[lane * 8 + j] = hi;
         d[512 + lane * 8 + j] = (bf16_t)(v - (float)hi);
@@ -738,41 +742,41 @@ LFT_DEV long long up_token(int b, int Ym, int Xm, int A, int h, int w, int s, in
     const int a1 = ly / h, a2 = lx / w;
     return (((long long)b * A * A + a1 * A + a2) * h + (ly - a1 * h)) * w + (lx - a2 * w);
 }
-// Backward of the tail.  One wave per item = (token, sub-pixel); lane = channel c.
-//   dU[t][c*ss + sub] = lrelu'(Aact) * sum_tap w3[c][tap] * dout[Ym - dy][Xm - dx]
-//   dw3[c][tap]      += Aact[t][c*ss + sub] * dout[Ym - dy][Xm - dx]
-// Each wave walks a contiguous range of items and leaves its 64 x 9 partial sums in part[wave][576].
-__global__ __launch_bounds__(256) void k_up_conv_bwd(const float* __restrict__ Aact, const float* __restrict__ w3,
-                                                     const float* __restrict__ dout, float* __restrict__ dU,
-                                                     float* __restrict__ part, int B, int A, int h, int w, int s,
-                                                     long long items_per_wave) {
-    const int c = threadIdx.x & 63, ss = s * s;
-    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int HH = A * h * s, WW = A * w * s, V = A * A;
-    const long long nitems = (long long)B * V * h * w * ss;
-    float wr[9], dw[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) { wr[t] = w3[c * 9 + t]; dw[t] = 0.0f; }
-    const long long i0 = wv * items_per_wave, i1 = min(i0 + items_per_wave, nitems);
-    for (long long it = i0; it < i1; ++it) {
-        const long long t = it / ss;
-        const int sub = (int)(it - t * ss);
-        const int x = (int)(t % w), y = (int)((t / w) % h), v = (int)((t / ((long long)w * h)) % V), b = (int)(t / ((long long)w * h * V));
-        const int Ym = ((v / A) * h + y) * s + sub / s, Xm = ((v % A) * w + x) * s + sub % s;
-        const float a = Aact[t * 64 * ss + c * ss + sub];
-        float g = 0.0f;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = Ym - (tap / 3 - 1), xx = Xm - (tap % 3 - 1);      // the output pixel that read F here through `tap`
-            const bool ok = yy >= 0 && yy < HH && xx >= 0 && xx < WW;
-            const float d = ok ? dout[((long long)b * HH + yy) * WW + xx] : 0.0f;
-            g += wr[tap] * d;
-            dw[tap] += a * d;
-        }
-        dU[t * 64 * ss + c * ss + sub] = a > 0.0f ? g : 0.2f * g;
+// Backward of the tail, mirroring its forward (G = M Aact, out = gather of footprints):
+//   dG[t][n]   = dout at the HR pixel that footprint entry n = (I+1)(S+2)+(J+1) of token t lands on (0 outside the mosaic,
+//                0 in the padding columns n >= (S+2)^2)                                              -- k_up_gather_bwd
+//   dAact      = M^T dG, times lrelu'  (k_lin with the transposed packed matrix and the activation epilogue)
+//   dM         = dG^T Aact             (k_wgrad), folded back onto the 64 x 3 x 3 weight by k_upm_fold:
+//                M[n(I,J)][c*ss + i*S + j] = w3[c][i-I+1][j-J+1]  =>  dw3[c][ty][tx] = sum_{i,j} dM[n(i-ty+1, j-tx+1)][c*ss + i*S + j]
+__global__ __launch_bounds__(256) void k_up_gather_bwd(const float* __restrict__ dout, float* __restrict__ dG, int B, int A, int h, int w,
+                                                       int s, int gld) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int V = A * A;
+    const long long N = (long long)B * V * h * w;
+    if (idx >= N * gld) return;
+    const long long t = idx / gld;
+    const int n = (int)(idx - t * gld), gp = (s + 2) * (s + 2);
+    float v = 0.0f;
+    if (n < gp) {
+        const int I = n / (s + 2) - 1, J = n % (s + 2) - 1;
+        const int x = (int)(t % w), y = (int)((t / w) % h), vv = (int)((t / ((long long)w * h)) % V), b = (int)(t / ((long long)w * h * V));
+        const int Y = ((vv / A) * h + y) * s + I, X = ((vv % A) * w + x) * s + J;
+        const int HH = A * h * s, WW = A * w * s;
+        if (Y >= 0 && Y < HH && X >= 0 && X < WW) v = dout[((long long)b * HH + Y) * WW + X];
     }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) part[wv * 576 + c * 9 + t] = dw[t];
+    dG[idx] = v;
+}
+__global__ void k_upm_fold(const float* __restrict__ dM, float* __restrict__ dw3, int s) {       // dM: [32 gt][64 s^2]
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 576) return;
+    const int c = idx / 9, ty = (idx % 9) / 3, tx = idx % 3, ss = s * s;
+    float acc = 0.0f;
+    for (int i = 0; i < s; ++i)
+        for (int j = 0; j < s; ++j) {
+            const int I = i - (ty - 1), J = j - (tx - 1);                        // always inside [-1, s]
+            acc += dM[(size_t)((I + 1) * (s + 2) + (J + 1)) * 64 * ss + c * ss + i * s + j];
+        }
+    dw3[idx] = acc;
 }
 
 // conv_init0 weight gradient (reference LFT.py:24): dW0[c][tap] = sum_t dX0[t][c] * lr[view pixel (y+dy, x+dx)].

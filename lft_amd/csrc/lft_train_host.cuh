@@ -33,7 +33,7 @@ inline ParamInfo param_info(int s) {
 }
 
 // ---- packed weight views: every matrix the step multiplies by, in both orientations, as k_pack fragment streams ----
-enum { VW_CONV_F = 0, VW_CONV_B = 3, VW_LAYER0 = 6, VW_PER_LAYER = 24, VW_UP_F = VW_LAYER0 + 4 * VW_PER_LAYER, VW_UP_B, VW_UPM, VW_COUNT };
+enum { VW_CONV_F = 0, VW_CONV_B = 3, VW_LAYER0 = 6, VW_PER_LAYER = 24, VW_UP_F = VW_LAYER0 + 4 * VW_PER_LAYER, VW_UP_B, VW_UPM, VW_UPM_B, VW_COUNT };
 enum { MLP_F = 0, MLP_B, SIN_F, SQK_B, SUNUSED, SV_B, SOUT_F, SOUT_B, SFF1_F, SFF1_B, SFF2_F, SFF2_B, SLIN_F, SLIN_B,
        AIN_F, AQK_B, AV_B, AOUT_F, AOUT_B, AFF1_F, AFF1_B, AFF2_F, AFF2_B };
 inline int vw(int l, int which) { return VW_LAYER0 + VW_PER_LAYER * l + which; }
@@ -84,6 +84,14 @@ WViews build_views(const float* const* P, int s, std::vector<PackOp>* ops) {
             m.kind = 1; m.s = s; m.ntiles = gt;
             ops->push_back(m);
         }
+        WView& vb = W.v[VW_UPM_B];                    // its transpose: 64 s^2 rows, 32 gt columns (the padding columns are zero)
+        vb.frag0 = W.nfrags; vb.OT = 2 * s * s; vb.KS = 2 * gt; vb.taps = 1;
+        W.nfrags += (size_t)vb.OT * vb.KS;
+        if (ops) {
+            PackOp m = lin_op(src(P_UP3), 0, 64 * s * s, 0, 0, vb.KS, 0, 1.0f);
+            m.kind = 2; m.s = s;
+            ops->push_back(m);
+        }
     }
     return W;
 }
@@ -129,13 +137,13 @@ TrainLayout train_layout(const Dims& d) {
     // Every gradient tensor of the backward pass gets its own buffer (no reuse): the weight-gradient kernels then only
     // depend on their producers and can run on a second stream beside the data-gradient chain.  Per token: the tail 64,
     // per layer 1728 (SpaTrans) + 704 (AngTrans), the feature extractor 320 floats; plus the 4 position-token gradients.
-    T.bwd_floats = n * (64 + (size_t)kLayers * (1728 + 704) + 320) + (size_t)kLayers * (((size_t)d.hw * 128 + 63) & ~(size_t)63);
+    T.bwd_floats = n * (64 + 64 + (size_t)kLayers * (1728 + 704) + 320) + (size_t)kLayers * (((size_t)d.hw * 128 + 63) & ~(size_t)63) + (size_t)64 * 64 * ss;
     T.bwd = take(T.bwd_floats);
     T.gu = take(n * 64 * ss);
     T.stats = take(n * 8 * 3);
     // every producer of partial sums gets its own region (one k_reduce_all launch at the end of the backward pass):
     // weight gradients (all parameters + the position-token share of the 4 embedding weights), 16 LayerNorms, 2 tails
-    T.part_floats = (size_t)wg_chunks(d.ntok) * ((size_t)param_info(d.s).total + 64) + (size_t)4 * wg_chunks(d.hw) * 128 * 576
+    T.part_floats = (size_t)wg_chunks(d.ntok) * ((size_t)param_info(d.s).total + 64 + (size_t)64 * 64 * ss) + (size_t)4 * wg_chunks(d.hw) * 128 * 576
                     + (size_t)16 * kLnBlocks * 256 + (size_t)2 * kTailWaves * 576;
     T.part = take(T.part_floats);
     T.pgb = 0;
@@ -429,16 +437,16 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
     auto g = [&](int idx) { return G + pi.off[idx]; };
     size_t soff = 0;
     auto nb = [&](int width) { float* p = c.F(T.bwd) + soff; soff += (size_t)N * width; return p; };   // fresh [N][width] gradient buffer
-    // ---- up-sampler tail ----
+    // ---- up-sampler tail (the transpose of its forward: gather, GEMM with the overlap-add matrix) ----
     float* gu = c.F(T.gu);
-    {
-        const long long nitems = N * ss, per = (nitems + kTailWaves - 1) / kTailWaves;
-        const size_t poff = part_used;
-        part_used += (size_t)kTailWaves * 576;
-        k_up_conv_bwd<<<kTailWaves / 4, 256, 0, st>>>(c.F(T.act), P[P_UP3], dout, gu, c.F(T.part) + poff, d.B, d.A, d.h, d.w, d.s, per);
-        LFT_LAUNCH_OK("k_up_conv_bwd");
-        TRY(red_push(c, poff, kTailWaves, 576, 576, g(P_UP3), 0));
-    }
+    const int gt = (d.gp + 31) / 32;
+    float* dG = nb(32 * gt);
+    k_up_gather_bwd<<<blocks_for(N * 32 * gt, 256), 256, 0, st>>>(dout, dG, d.B, d.A, d.h, d.w, d.s, 32 * gt);
+    LFT_LAUNCH_OK("k_up_gather_bwd");
+    float* dM = c.F(T.bwd) + soff;                                   // [32 gt][64 s^2], folded onto upsampling.3.weight at the end
+    soff += (size_t)32 * gt * 64 * ss;
+    TRY(wgrad(c, dG, 32 * gt, c.F(T.act), 64 * ss, 1, dM, 0, N));
+    TRY(run_lin(c, VW_UPM_B, 0, 0, dG, 32 * gt, 0, 0, nullptr, 0, gu, 64 * ss, N, c.F(T.act), 2));   // dU = (M^T dG) * lrelu'(U)
     TRY(wgrad(c, gu, 64 * ss, c.F(T.body), 64, 1, g(P_UP0), 0, N));
     float* gskip = nb(64);
     TRY(lin_bwd(c, VW_UP_B, gu, nullptr, gskip, N));                 // d body = d y3 = d feat (global skip)
@@ -549,6 +557,8 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
     }
     k_reduce_all<<<red.nblk, 256, 0, st>>>(red, c.F(T.part), G);      // every gradient's partial sums, one launch
     LFT_LAUNCH_OK("k_reduce_all");
+    k_upm_fold<<<3, 256, 0, st>>>(dM, g(P_UP3), d.s);
+    LFT_LAUNCH_OK("k_upm_fold");
 #undef TRY
     return 0;
 }
