@@ -4,6 +4,7 @@
 #include "lft_kernels_a.cuh"
 #include "lft_kernels_b.cuh"
 #include "lft_metrics.cuh"
+#include "lft_train.cuh"     // training kernels; the fp32 inference path shares their LDS-tiled window attention
 
 #include <cstdarg>
 #include <cstdio>
@@ -357,7 +358,12 @@ int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, con
         k_spa_attn_mfma<<<ntile, 256, kAmLds, st>>>(q, k, v, o, d.h, d.w);
 #endif
     } else {
-        k_spa_attn<T><<<blocks_for(d.ntok * 8, 256), 256, 0, st>>>(q, k, v, o, d.ntok, d.h, d.w);
+        // fp32: the LDS-tiled window attention of the training step (8 x 16 query tile x head pair per workgroup), Q pre-scaled
+        const unsigned tiles = (unsigned)(((d.w + kWaTX - 1) / kWaTX) * ((d.h + kWaTY - 1) / kWaTY) * nimg);
+        if ((rc = allow_lds(k_win_attn_lds<0, true>, kWaLds, "k_win_attn_lds"))) return rc;
+        k_win_attn_lds<0, true><<<dim3(tiles, 4), 256, kWaLds, st>>>(reinterpret_cast<const float*>(q), reinterpret_cast<const float*>(k),
+                                                                     reinterpret_cast<const float*>(v), reinterpret_cast<float*>(o),
+                                                                     nullptr, nullptr, nullptr, nullptr, nullptr, d.h, d.w, 128);
     }
     LFT_LAUNCH_OK("k_spa_attn");
     const unsigned nb = blocks_for(d.ntok, 128);

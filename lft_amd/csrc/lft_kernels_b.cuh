@@ -105,137 +105,19 @@ __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa1(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// SpaTrans windowed attention core (reference LFT.py:147-162 mask + :183-187 attention).
-// One thread = (token, head): 16-dim head, keys = clamped 5x5 window around the query.
-// The reference bounds the window columns by min(h, x+3) (LFT.py:155, "h" where "w" is meant) and
-// slicing clips at w; reproduced as-is: for h < w some queries see no key and come out NaN, as in
-// the reference.  Q is pre-scaled by scale*log2(e); softmax uses exp2.
+// SpaTrans windowed attention core (reference LFT.py:147-162 mask + :183-187 attention): keys = clamped 5x5 window around
+// the query.  The reference bounds the window columns by min(h, x+3) (LFT.py:155, "h" where "w" is meant) and slicing
+// clips at w; reproduced as-is: for h < w some queries see no key at all and get a zero attention output (what the
+// reference gives under torch >= 2.5).  Q is pre-scaled by scale*log2(e); softmax uses exp2.
 // ------------------------------------------------------------------------------------------
-template <typename T> LFT_DEV void load16(const T* p, float (&o)[16]) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 v = load4(p + 4 * g);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[4 * g + j] = v[j];
-    }
-}
-template <typename T>
-__global__ __launch_bounds__(256) void k_spa_attn(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ Vv,
-                                                  T* __restrict__ O, long long ntok, int h, int w) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long tok = idx >> 3;
-    const int head = (int)(idx & 7);
-    if (tok >= ntok) return;
-    const int hw = h * w;
-    const int p = (int)(tok % hw);
-    const long long img0 = tok - p;
-    const int y = p / w, x = p % w;
-    const int y0 = max(0, y - 2), y1 = min(h, y + 3), x0 = max(0, x - 2), x1 = min(min(h, x + 3), w);
-    float q[16], kv[16], s[25];
-    load16<T>(Q + tok * 128 + head * 16, q);
-    float m = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 25; ++t) {
-        const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
-        s[t] = -INFINITY;
-        if (ky >= y0 && ky < y1 && kx >= x0 && kx < x1) {
-            load16<T>(K + (img0 + ky * w + kx) * 128 + head * 16, kv);
-            float d = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) d += q[c] * kv[c];
-            s[t] = d;
-        }
-        m = fmaxf(m, s[t]);
-    }
-    float sum = 0.0f, o[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) o[c] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 25; ++t) {
-        const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
-        if (s[t] != -INFINITY) {
-            const float pr = fast_exp2(s[t] - m);
-            sum += pr;
-            load16<T>(Vv + (img0 + ky * w + kx) * 128 + head * 16, kv);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) o[c] += pr * kv[c];
-        }
-    }
-    // empty window (only possible for h < w, see above): the reference run under torch >= 2.5 (the version that generated
-    // tests/golden) gives a ZERO attention output for a fully masked row ("safe softmax" in F.scaled_dot_product_attention);
-    // older torch gave NaN.  We follow the pinned behaviour: sum == 0 -> 0.
-    const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-        store4(O + tok * 128 + head * 16 + 4 * g, f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv});
-}
-
-// bf16 specialisation: the head's 16 channels stay packed (8 x bf16 pairs); Q.K uses v_dot2c_f32_bf16 on the raw
-// pairs (no unpacking), and P.V accumulates with the same instruction against (p, 0) / (0, p) so V is never
-// unpacked either: ~700 VALU instructions per (query, head) instead of ~2500.  P is rounded to bf16 as an MFMA
-// operand would be; all accumulation is fp32.
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 LFT_DEV void load_pairs16(const bf16_t* p, bf16x2 (&o)[8]) {
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(p), b = *reinterpret_cast<const bf16x8*>(p + 8);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o[i] = bf16x2{a[2 * i], a[2 * i + 1]}; o[4 + i] = bf16x2{b[2 * i], b[2 * i + 1]}; }
 }
-template <>
-__global__ __launch_bounds__(256) void k_spa_attn<bf16_t>(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                          const bf16_t* __restrict__ Vv, bf16_t* __restrict__ O, long long ntok,
-                                                          int h, int w) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long tok = idx >> 3;
-    const int head = (int)(idx & 7);
-    if (tok >= ntok) return;
-    const int hw = h * w;
-    const int p = (int)(tok % hw);
-    const long long img0 = tok - p;
-    const int y = p / w, x = p % w;
-    const int y0 = max(0, y - 2), y1 = min(h, y + 3), x0 = max(0, x - 2), x1 = min(min(h, x + 3), w);
-    bf16x2 q[8], kv[8];
-    float s[25];
-    load_pairs16(Q + tok * 128 + head * 16, q);
-    float m = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 25; ++t) {
-        const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
-        s[t] = -INFINITY;
-        if (ky >= y0 && ky < y1 && kx >= x0 && kx < x1) {
-            load_pairs16(K + (img0 + ky * w + kx) * 128 + head * 16, kv);
-            float d = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) d = __builtin_amdgcn_fdot2_f32_bf16(q[c], kv[c], d, false);
-            s[t] = d;
-        }
-        m = fmaxf(m, s[t]);
-    }
-    float sum = 0.0f, o[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) o[c] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 25; ++t) {
-        const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
-        if (s[t] != -INFINITY) {
-            const float pr = fast_exp2(s[t] - m);
-            sum += pr;
-            const bf16_t pb = (bf16_t)pr;
-            const bf16x2 p0 = bf16x2{pb, (bf16_t)0.0f}, p1 = bf16x2{(bf16_t)0.0f, pb};
-            load_pairs16(Vv + (img0 + ky * w + kx) * 128 + head * 16, kv);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                o[2 * c] = __builtin_amdgcn_fdot2_f32_bf16(p0, kv[c], o[2 * c], false);
-                o[2 * c + 1] = __builtin_amdgcn_fdot2_f32_bf16(p1, kv[c], o[2 * c + 1], false);
-            }
-        }
-    }
-    const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;      // empty window -> 0, see the generic kernel
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-        store4(O + tok * 128 + head * 16 + 4 * g, f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv});
-}
-
-// LDS-tiled bf16 windowed attention (the production path; the per-thread kernels above remain for fp32).
+// LDS-tiled bf16 windowed attention on the VALU (v_dot2c): superseded by the MFMA kernel below, kept for A/B builds
+// (-DLFT_ATT_VALU).  The fp32 path uses the LDS-tiled kernel of lft_train.cuh (k_win_attn_lds<0, true>).
 // A 512-thread workgroup owns a 4 x 32 tile of queries of one view image and 4 of the 8 heads (64 channels).
 // The (4+4) x (32+4) halo tile of K -- then of V, re-using the same 41 KiB -- is staged once into LDS (every key is
 // used by up to 25 queries x 4 heads), token rows padded to 144 B so the 16-byte reads of a half-wave (32 different

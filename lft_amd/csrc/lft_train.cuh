@@ -620,7 +620,7 @@ LFT_DEV void lds16(const float* p, float (&o)[16]) {
         for (int j = 0; j < 4; ++j) o[4 * g + j] = v[j];
     }
 }
-template <int MODE>
+template <int MODE, bool PRESCALED = false>   // PRESCALED: Q already carries 1/sqrt(16) * log2(e) (the inference path folds it into Wq)
 __global__ __launch_bounds__(256, 2) void k_win_attn_lds(const float* __restrict__ Q, const float* __restrict__ K,
                                                          const float* __restrict__ Vv, float* __restrict__ O,
                                                          const float* __restrict__ dO, float* __restrict__ dQ, float* __restrict__ dK,
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void k_win_attn_lds(const float* __restrict
     const bool valid = y < h && x < w;
     const long long tok = img0 + min(y, h - 1) * w + min(x, w - 1);
     const size_t off = (size_t)tok * 128 + hp * 32 + hl * 16, offq = (size_t)tok * ldq + hp * 32 + hl * 16;
-    const float scale = 0.25f, scale2 = 0.25f * LFT_LOG2E;
+    const float scale = 0.25f, scale2 = PRESCALED ? 1.0f : 0.25f * LFT_LOG2E;
     wa_stage(MODE == 2 ? Q : K, ldq, tA, img0, y0, x0, hp, h, w);
     wa_stage(MODE == 2 ? dO : Vv, 128, tB, img0, y0, x0, hp, h, w);
     if (MODE == 2) {
