@@ -44,6 +44,7 @@ def flops_per_token(s: int, V: int, wbar: float) -> dict:
         "k_spa1": 18 * C * E + 6 * E * E,
         "k_spa_attn": 4 * wbar * E,
         "k_spa2": 2 * E * E + 8 * E * E + 2 * E * C,
+        "k_spa_b": 4 * wbar * E + 2 * E * E + 8 * E * E + 2 * E * C,     # bf16: attention + out_proj + FFN + 1x1x1 in one kernel
         "k_up": 2 * C * C * s * s + 18 * C * s * s,
         "k_assemble": 32 * s * s,
     }
@@ -60,6 +61,7 @@ def bytes_per_token(s: int, esz: int) -> dict:
         "k_spa1": C * esz + 4 * E * esz,              # x in; tok, Q, K, V out
         "k_spa_attn": 4 * E * esz,                    # Q, K, V in (halo re-reads are not algorithmic); O out
         "k_spa2": 2 * E * esz + C * esz,              # tok, O in; x out
+        "k_spa_b": 4 * E * esz + C * esz,             # tok, Q, K, V in (halo re-reads are not algorithmic); x out
         "k_up": C * esz + gp * 4,                     # x in; (s+2)^2 fp32 footprint out
         "k_assemble": gp * 4 + 4 + s * s * 4,         # footprint + LR pixel in; s*s HR pixels out
     }
@@ -161,7 +163,17 @@ def main():
     rank, local, world = dp.env_world()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+            # Plain `python bench.py --gpus N`: start the N ranks ourselves, as child processes of a parent that never
+            # touches the GPU (nothing below this point has run yet), and leave with the launcher's exit code.
+            import socket
+            import subprocess
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            note("spawning: " + " ".join(cmd))
+            raise SystemExit(subprocess.call(cmd))
         args.gpus = world
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

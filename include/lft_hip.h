@@ -69,6 +69,13 @@ int lft_forward_profiled(const void* packed, const float* lr, float* out, void* 
                          int B, int A, int h, int w, int s, int prec, void* stream,
                          int max_records, float* ms_out, const char** names_out, int* n_out);
 
+/* Measurement aid for bench.py's roofline: mean milliseconds of ONE kernel of the forward ("k_conv64", "k_ang", "k_spa1",
+ * "k_spa_b"), launched `reps` times back to back between two HIP events on `stream` -- no event between the launches,
+ * so the figure is comparable with a rocprofv3 kernel trace.  The kernel reads what a previous lft_forward left in
+ * `workspace`.  Synchronises `stream`. */
+int lft_kernel_time(const char* kernel, const void* packed, void* workspace, int B, int A, int h, int w, int s, int prec,
+                    int reps, void* stream, float* ms_out);
+
 /* ---- per-stage entry points (unit tests, profiling).  `act` buffers are channels-last
  * [B, A*A, h, w, 64] in the activation type of `prec` (float or __bf16). ---- */
 

@@ -92,7 +92,7 @@ PackedLayout packed_layout(const Dims& d, int prec) {
     L.conv0_w = take(576 * 4);
     for (int l = 0; l < kLayers; ++l) { L.ln_ang[l] = take(256 * 4); L.ln_spa[l] = take(512 * 4); }
     L.ang_pe = take((size_t)((d.V + 31) / 32) * 2048 * 4);                       // lane-major, per 32-view tile
-    for (int l = 0; l < kLayers; ++l) L.petok[l] = take((size_t)((d.hw + 127) / 128) * 4 * 4096 * esz);   // lane-major, per 32-token tile
+    for (int l = 0; l < kLayers; ++l) L.petok[l] = take((size_t)((d.hw + 32 * kNwSpa1 - 1) / (32 * kNwSpa1)) * kNwSpa1 * 4096 * esz);   // lane-major, per 32-token tile
     L.spa_pe_img = take((size_t)d.hw * 64 * esz);
     for (int i = 0; i < 3; ++i) L.s_conv[i] = take(kFragsConv * fragb);
     for (int l = 0; l < kLayers; ++l) {
@@ -123,12 +123,13 @@ WorkLayout work_layout(const Dims& d, int prec) {
 }
 
 // Dynamic LDS sizes (bytes) and the opt-in above the 64 KiB default (a workgroup may use all 160 KiB of a CU).
-template <typename T> size_t lds_conv64(int w) { return WRing<T, kConv64Chunk>::LDS_BYTES + ConvIn<T>::bytes(w) + 4 * TileIO<2, T>::BYTES; }
+template <typename T> size_t lds_conv64(int w) { return WRing<T, kConv64Chunk, kNwConv>::LDS_BYTES + ConvIn<T, kNwConv>::bytes(w) + kNwConv * TileIO<2, T>::BYTES; }
 constexpr size_t kLdsParams = 1024;   // 256 LayerNorm floats
-template <typename T, int CH = kSpaChunk> size_t lds_spa1(int w) { return WRing<T, CH>::LDS_BYTES + ConvIn<T>::bytes(w) + kLdsParams; }
-template <typename T> size_t lds_ring() { return WRing<T, kSpaChunk>::LDS_BYTES + kLdsParams; }
-template <typename T> size_t lds_spa2() { return WRing<T, kSpaChunk>::LDS_BYTES + kLdsParams + 4 * TileIO<4, T>::BYTES; }
-template <typename T> size_t lds_up() { return WRing<T, kUpChunk>::LDS_BYTES + 4 * TileIO<2, T>::BYTES; }
+template <typename T, int CH = kSpaChunk> size_t lds_spa1(int w) {      // the tile I/O scratch aliases the conv input tile, which must be large enough for it
+    return WRing<T, CH, kNwSpa1>::LDS_BYTES + std::max<size_t>(ConvIn<T, kNwSpa1>::bytes(w), (size_t)kNwSpa1 * TileIO<4, T>::BYTES) + kLdsParams;
+}
+template <typename T> size_t lds_spa2() { return WRing<T, kSpaChunk, kNwSpa2>::LDS_BYTES + kLdsParams + kNwSpa2 * TileIO<4, T>::BYTES; }
+template <typename T> size_t lds_up() { return WRing<T, kUpChunk, kNwUp>::LDS_BYTES + kNwUp * TileIO<2, T>::BYTES; }
 template <typename T> size_t lds_ang() { return (size_t)kFragsAng * 1024 * FragInfo<T>::PIECES + kLdsParams + 4 * TileIO<2, T>::BYTES; }
 constexpr size_t kMaxLds = 160 * 1024;
 template <typename K> int allow_lds(K kernel, size_t bytes, const char* name) {
@@ -196,11 +197,11 @@ int launch_spa1(unsigned nwg, const T* in, const T* ws, const float* ln, const T
 #ifndef LFT_YLM
 #define LFT_YLM 1
 #endif
-    const bool lm = LFT_TOKLM && !PE_ONLY && d.hw % 128 == 0;      // full tiles everywhere: hand the token tile to k_spa2 in lane-major form
+    const bool lm = LFT_TOKLM && !PE_ONLY && sizeof(T) == 4 && d.hw % (32 * kNwSpa1) == 0;      // fp32, full tiles everywhere: hand the token tile to k_spa2 in lane-major form (bf16: k_spa_b reads row-major 8 x 4 blocks)
 #define LFT_LAUNCH_SPA1(CHV, LMV, LDSV)                                                                                     \
     do {                                                                                                                    \
         if ((rc = allow_lds(k_spa1<T, PE_ONLY, CHV, LMV>, LDSV, "k_spa1"))) return rc;                                      \
-        k_spa1<T, PE_ONLY, CHV, LMV><<<nwg, 256, LDSV, st>>>(in, ws, ln, petok, tok, q, k, v, pe_out, nimg, d.h, d.w);      \
+        k_spa1<T, PE_ONLY, CHV, LMV><<<nwg, 64 * kNwSpa1, LDSV, st>>>(in, ws, ln, petok, tok, q, k, v, pe_out, nimg, d.h, d.w); \
     } while (0)
     if (use8) { if (lm) LFT_LAUNCH_SPA1(8, true, l8); else LFT_LAUNCH_SPA1(8, false, l8); }
     else { if (lm) LFT_LAUNCH_SPA1(16, true, l16); else LFT_LAUNCH_SPA1(16, false, l16); }
@@ -252,9 +253,10 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
             ops.push_back(lin_op(q[3], 128, 128, 128, 0, 8, 1, 1.0f));          // Wk
             if ((rc = run_pack<T>(ops, at<T>(packed, L.s_spa1[l]), kFragsSpa1, st))) return rc;
         }
-        {   // spatial part 2: out_proj (operand from memory: natural k), FFN in 4 chunks, 1x1x1 conv
+        {   // spatial part 2: out_proj, FFN in 4 chunks, 1x1x1 conv.  out_proj's operand: bf16 -- the attention accumulators
+            // inside k_spa_b (acc order); fp32 -- the attention output read back from memory by k_spa2 (natural k)
             std::vector<PackOp> ops;
-            ops.push_back(lin_op(q[4], 0, 128, 128, 0, 8, 0, 1.0f));
+            ops.push_back(lin_op(q[4], 0, 128, 128, 0, 8, sizeof(T) == 2 ? 1 : 0, 1.0f));
             for (int c = 0; c < 4; ++c) {
                 ops.push_back(lin_op(q[7], 64 * c, 64, 128, 0, 8, 1, 1.0f));
                 ops.push_back(lin_op(q[8], 0, 128, 256, 64 * c, 4, 1, 1.0f));
@@ -263,7 +265,7 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
             if ((rc = run_pack<T>(ops, at<T>(packed, L.s_spa2[l]), kFragsSpa2, st))) return rc;
         }
         // embedded spatial position tokens of this layer (reference LFT.py:180), [h*w][128] in the activation type
-        if ((rc = launch_spa1<T, true>((unsigned)((d.hw + 127) / 128), at<T>(packed, L.spa_pe_img), at<T>(packed, L.s_spa1[l]), nullptr, nullptr,
+        if ((rc = launch_spa1<T, true>((unsigned)((d.hw + 32 * kNwSpa1 - 1) / (32 * kNwSpa1)), at<T>(packed, L.spa_pe_img), at<T>(packed, L.s_spa1[l]), nullptr, nullptr,
                                        nullptr, nullptr, nullptr, nullptr, at<T>(packed, L.petok[l]), 1, d, st))) return rc;
         LFT_LAUNCH_OK("k_spa1<pe>");
     }
@@ -280,34 +282,28 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
     return 0;
 }
 
-void launch_assemble(const float* lr, const float* g, float* out, int B, int A, int h, int w, int s, int with_body, hipStream_t st, int gld = 0) {
-    if (with_body) {                                    // tiled gather: 8 x 8 LR mosaic pixels per workgroup
-        const dim3 tg((unsigned)((A * w + 7) / 8), (unsigned)((A * h + 7) / 8), (unsigned)B);
-        if (!gld) gld = (s + 2) * (s + 2);
-        if (s == 2) k_assemble_t<2><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w, gld);
-        else k_assemble_t<4><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w, gld);
-        return;
-    }
-    const dim3 grid((unsigned)((A * w * s + 255) / 256), (unsigned)(A * h * s), (unsigned)B);
-    if (s == 2) k_assemble<2><<<grid, 256, 0, st>>>(lr, g, out, B, A, h, w, with_body);
-    else k_assemble<4><<<grid, 256, 0, st>>>(lr, g, out, B, A, h, w, with_body);
+void launch_assemble(const float* lr, const float* g, float* out, int B, int A, int h, int w, int s, hipStream_t st, int gld = 0) {
+    const dim3 tg((unsigned)((A * w + 7) / 8), (unsigned)((A * h + 7) / 8), (unsigned)B);      // 8 x 8 LR mosaic pixels per workgroup
+    if (!gld) gld = (s + 2) * (s + 2);
+    if (s == 2) k_assemble_t<2><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w, gld);
+    else k_assemble_t<4><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w, gld);
 }
 
 // ---------------------------------------------------------------------------- stages
 template <typename T>
 int init_features(const void* packed, const PackedLayout& L, const float* lr, T* x0, T* ta, T* tb, T* feat, const Dims& d, hipStream_t st) {
-    const int nimg = d.B * d.V, nwg = nimg * ((d.hw + 127) / 128);
+    const int nimg = d.B * d.V, nwg = nimg * ((d.hw + 32 * kNwConv - 1) / (32 * kNwConv));
     const size_t lds = lds_conv64<T>(d.w);
     int rc;
     if ((rc = allow_lds(k_conv64<T, false>, lds, "k_conv64"))) return rc;
     if ((rc = allow_lds(k_conv64<T, true>, lds, "k_conv64"))) return rc;
     k_conv0<T><<<dim3((unsigned)((d.hw + 31) / 32), (unsigned)nimg), 256, 0, st>>>(lr, at<float>(packed, L.conv0_w), x0, d.B, d.A, d.h, d.w);
     LFT_LAUNCH_OK("k_conv0");
-    k_conv64<T, false><<<nwg, 256, lds, st>>>(x0, ta, nullptr, at<T>(packed, L.s_conv[0]), nimg, d.h, d.w);
+    k_conv64<T, false><<<nwg, 64 * kNwConv, lds, st>>>(x0, ta, nullptr, at<T>(packed, L.s_conv[0]), nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_conv64");
-    k_conv64<T, false><<<nwg, 256, lds, st>>>(ta, tb, nullptr, at<T>(packed, L.s_conv[1]), nimg, d.h, d.w);
+    k_conv64<T, false><<<nwg, 64 * kNwConv, lds, st>>>(ta, tb, nullptr, at<T>(packed, L.s_conv[1]), nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_conv64");
-    k_conv64<T, true><<<nwg, 256, lds, st>>>(tb, feat, x0, at<T>(packed, L.s_conv[2]), nimg, d.h, d.w);
+    k_conv64<T, true><<<nwg, 64 * kNwConv, lds, st>>>(tb, feat, x0, at<T>(packed, L.s_conv[2]), nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_conv64");
     return 0;
 }
@@ -341,22 +337,36 @@ int ang_block(const void* packed, const PackedLayout& L, int l, const T* in, T* 
     LFT_LAUNCH_OK("k_ang");
     return 0;
 }
+// SpaTrans = part A (k_spa1: token embedding, LayerNorm, Q / K / V) + part B (attention and the per-token tail).
 template <typename T>
-int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, const T* skip, T* out, void* ws, const WorkLayout& W,
-              const Dims& d, hipStream_t st, bool out_lm = false) {      // out_lm: lane-major output tiles, only for the up-sampler
-    const int nimg = d.B * d.V, nwg = nimg * ((d.hw + 127) / 128);
+int spa_part_a(const void* packed, const PackedLayout& L, int l, const T* in, void* ws, const WorkLayout& W, const Dims& d, hipStream_t st) {
+    const int nimg = d.B * d.V, nwg = nimg * ((d.hw + 32 * kNwSpa1 - 1) / (32 * kNwSpa1));
+    int rc;
+    if ((rc = launch_spa1<T, false>((unsigned)nwg, in, at<T>(packed, L.s_spa1[l]), at<float>(packed, L.ln_spa[l]), at<T>(packed, L.petok[l]),
+                                    at<T>(ws, W.tok), at<T>(ws, W.q), at<T>(ws, W.k), at<T>(ws, W.v), nullptr, nimg, d, st))) return rc;
+    LFT_LAUNCH_OK("k_spa1");
+    return 0;
+}
+template <typename T>
+int spa_part_b(const void* packed, const PackedLayout& L, int l, const T* skip, T* out, void* ws, const WorkLayout& W,
+               const Dims& d, hipStream_t st, bool out_lm = false) {      // out_lm: lane-major output tiles, only for the up-sampler
+    const int nimg = d.B * d.V;
     T *tok = at<T>(ws, W.tok), *q = at<T>(ws, W.q), *k = at<T>(ws, W.k), *v = at<T>(ws, W.v), *o = at<T>(ws, W.o);
     const float* ln = at<float>(packed, L.ln_spa[l]);
     int rc;
-    if ((rc = launch_spa1<T, false>((unsigned)nwg, in, at<T>(packed, L.s_spa1[l]), ln, at<T>(packed, L.petok[l]), tok, q, k, v, nullptr, nimg, d, st))) return rc;
-    LFT_LAUNCH_OK("k_spa1");
     if constexpr (sizeof(T) == 2) {
+        // bf16: windowed attention + out_proj + FFN + 1x1x1 conv in ONE kernel (the attention output stays in registers)
         const unsigned ntile = (unsigned)(nimg * ((d.h + kAttTY - 1) / kAttTY) * ((d.w + kAttTX - 1) / kAttTX));
-#ifdef LFT_ATT_VALU       // A/B: the LDS-tiled VALU (v_dot2c) kernel
-        k_spa_attn_lds<<<dim3(ntile, 2), kAttThreads, kAttLds, st>>>(q, k, v, o, d.h, d.w);
-#else
-        k_spa_attn_mfma<<<ntile, 256, kAmLds, st>>>(q, k, v, o, d.h, d.w);
-#endif
+        const size_t lds = kSpaBLds;
+        if (skip) {
+            if ((rc = allow_lds(k_spa_b<true>, lds, "k_spa_b"))) return rc;
+            k_spa_b<true><<<ntile, 256, lds, st>>>(tok, q, k, v, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.h, d.w);
+        } else {
+            if ((rc = allow_lds(k_spa_b<false>, lds, "k_spa_b"))) return rc;
+            k_spa_b<false><<<ntile, 256, lds, st>>>(tok, q, k, v, at<T>(packed, L.s_spa2[l]), ln, nullptr, out, d.h, d.w);
+        }
+        LFT_LAUNCH_OK("k_spa_b");
+        return 0;
     } else {
         // fp32: the LDS-tiled window attention of the training step (8 x 16 query tile x head pair per workgroup), Q pre-scaled
         const unsigned tiles = (unsigned)(((d.w + kWaTX - 1) / kWaTX) * ((d.h + kWaTY - 1) / kWaTY) * nimg);
@@ -364,14 +374,13 @@ int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, con
         k_win_attn_lds<0, true><<<dim3(tiles, 4), 256, kWaLds, st>>>(reinterpret_cast<const float*>(q), reinterpret_cast<const float*>(k),
                                                                      reinterpret_cast<const float*>(v), reinterpret_cast<float*>(o),
                                                                      nullptr, nullptr, nullptr, nullptr, nullptr, d.h, d.w, 128);
-    }
     LFT_LAUNCH_OK("k_spa_attn");
-    const unsigned nb = blocks_for(d.ntok, 128);
-    const bool lm = LFT_TOKLM && d.hw % 128 == 0;      // must match launch_spa1's choice
+    const unsigned nb = blocks_for(d.ntok, 32 * kNwSpa2);
+    const bool lm = LFT_TOKLM && sizeof(T) == 4 && d.hw % (32 * kNwSpa1) == 0;      // must match launch_spa1's choice
 #define LFT_LAUNCH_SPA2(SKV, LMV, YLV)                                                                                      \
     do {                                                                                                                    \
         if ((rc = allow_lds(k_spa2<T, SKV, LMV, YLV>, lds_spa2<T>(), "k_spa2"))) return rc;                                 \
-        k_spa2<T, SKV, LMV, YLV><<<nb, 256, lds_spa2<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.ntok); \
+        k_spa2<T, SKV, LMV, YLV><<<nb, 64 * kNwSpa2, lds_spa2<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.ntok); \
     } while (0)
     if (out_lm && !(skip && lm)) return fail(LFT_ERR_ARG, "internal: lane-major output needs the skip variant and full tiles");
     if (skip) { if (out_lm) LFT_LAUNCH_SPA2(true, true, true); else if (lm) LFT_LAUNCH_SPA2(true, true, false); else LFT_LAUNCH_SPA2(true, false, false); }
@@ -379,23 +388,31 @@ int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, con
 #undef LFT_LAUNCH_SPA2
     LFT_LAUNCH_OK("k_spa2");
     return 0;
+    }
+}
+template <typename T>
+int spa_block(const void* packed, const PackedLayout& L, int l, const T* in, const T* skip, T* out, void* ws, const WorkLayout& W,
+              const Dims& d, hipStream_t st, bool out_lm = false) {
+    int rc;
+    if ((rc = spa_part_a<T>(packed, L, l, in, ws, W, d, st))) return rc;
+    return spa_part_b<T>(packed, L, l, skip, out, ws, W, d, st, out_lm);
 }
 template <typename T>
 int upsample(const void* packed, const PackedLayout& L, const T* body, const float* lr, float* out, void* ws, const WorkLayout& W,
              const Dims& d, hipStream_t st, bool in_lm = false) {
     float* g = at<float>(ws, W.g);
-    const unsigned nb = blocks_for(d.ntok, 128);
+    const unsigned nb = blocks_for(d.ntok, 32 * kNwUp);
     int rc;
 #define LFT_LAUNCH_UP(GTV, LMV)                                                                                              \
     do {                                                                                                                    \
         if ((rc = allow_lds(k_up<T, GTV, LMV>, lds_up<T>(), "k_up"))) return rc;                                            \
-        k_up<T, GTV, LMV><<<nb, 256, lds_up<T>(), st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);            \
+        k_up<T, GTV, LMV><<<nb, 64 * kNwUp, lds_up<T>(), st>>>(body, at<T>(packed, L.s_up), g, d.ntok, d.nchunk, d.gp);     \
     } while (0)
     if (d.gt == 1) { if (in_lm) LFT_LAUNCH_UP(1, true); else LFT_LAUNCH_UP(1, false); }
     else { if (in_lm) LFT_LAUNCH_UP(2, true); else LFT_LAUNCH_UP(2, false); }
 #undef LFT_LAUNCH_UP
     LFT_LAUNCH_OK("k_up");
-    launch_assemble(lr, g, out, d.B, d.A, d.h, d.w, d.s, 1, st);
+    launch_assemble(lr, g, out, d.B, d.A, d.h, d.w, d.s, st);
     LFT_LAUNCH_OK("k_assemble");
     return 0;
 }
@@ -411,12 +428,52 @@ int forward_impl(const void* packed, const float* lr, float* out, void* ws, cons
     for (int l = 0; l < kLayers; ++l) {                  // angular first, then spatial (reference LFT.py:249-250)
         if ((rc = ang_block<T>(packed, L, l, cur, xa, d, st))) return rc;
         const bool last = l == kLayers - 1;                  // its output only feeds the up-sampler: same 32-token tiling, lane-major tiles
-        if ((rc = spa_block<T>(packed, L, l, xa, last ? feat : nullptr, xb, ws, W, d, st, last && LFT_TOKLM && LFT_YLM && d.hw % 128 == 0))) return rc;
+        if ((rc = spa_block<T>(packed, L, l, xa, last ? feat : nullptr, xb, ws, W, d, st, last && LFT_TOKLM && LFT_YLM && sizeof(T) == 4 && d.hw % (32 * kNwSpa1) == 0))) return rc;
         cur = xb;
     }
-    return upsample<T>(packed, L, xb, lr, out, ws, W, d, st, LFT_TOKLM && LFT_YLM && d.hw % 128 == 0);
+    return upsample<T>(packed, L, xb, lr, out, ws, W, d, st, LFT_TOKLM && LFT_YLM && sizeof(T) == 4 && d.hw % (32 * kNwSpa1) == 0);
 }
 
+// Mean duration of ONE kernel of the forward, launched `reps` times back to back between two HIP events on `stream` (no
+// event between launches, unlike lft_forward_profiled).  Inputs are whatever a previous lft_forward left in the
+// workspace.  Synchronises the stream.  kernel: "k_conv64", "k_ang", "k_spa1", "k_spa_b" (bf16) / "k_spa2" ... see below.
+template <typename T>
+int kernel_time_impl(const char* name, const void* packed, void* ws, const Dims& d, int prec, int reps, hipStream_t st, float* ms_out) {
+    const PackedLayout L = packed_layout(d, prec);
+    const WorkLayout W = work_layout(d, prec);
+    T *x0 = at<T>(ws, W.x0), *feat = at<T>(ws, W.feat), *xa = at<T>(ws, W.xa), *xb = at<T>(ws, W.xb);
+    const std::string k(name);
+    auto once = [&]() -> int {
+        if (k == "k_ang") return ang_block<T>(packed, L, 1, xb, xa, d, st);
+        if (k == "k_spa1") return spa_part_a<T>(packed, L, 1, xa, ws, W, d, st);
+        if (k == "k_spa_b" || k == "k_spa_attn+k_spa2") return spa_part_b<T>(packed, L, 1, nullptr, xb, ws, W, d, st);
+        if (k == "k_conv64") {
+            const int nimg = d.B * d.V, nwg = nimg * ((d.hw + 32 * kNwConv - 1) / (32 * kNwConv));
+            const size_t lds = lds_conv64<T>(d.w);
+            int rc;
+            if ((rc = allow_lds(k_conv64<T, false>, lds, "k_conv64"))) return rc;
+            k_conv64<T, false><<<nwg, 64 * kNwConv, lds, st>>>(x0, feat, nullptr, at<T>(packed, L.s_conv[0]), nimg, d.h, d.w);
+            LFT_LAUNCH_OK("k_conv64");
+            return 0;
+        }
+        return fail(LFT_ERR_ARG, "lft_kernel_time: unknown kernel %s", name);
+    };
+    int rc;
+    if ((rc = once())) return rc;                                     // warm (attributes, caches)
+    hipEvent_t e0, e1;
+    LFT_HIP_OK(hipEventCreate(&e0));
+    LFT_HIP_OK(hipEventCreate(&e1));
+    LFT_HIP_OK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps && !rc; ++i) rc = once();
+    LFT_HIP_OK(hipEventRecord(e1, st));
+    LFT_HIP_OK(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    LFT_HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    *ms_out = ms / (float)reps;
+    return 0;
+}
 #include "lft_train_host.cuh"
 
 }  // namespace
@@ -486,12 +543,23 @@ int lft_forward_profiled(const void* packed, const float* lr, float* out, void* 
     return 0;
 }
 
+int lft_kernel_time(const char* kernel, const void* packed, void* workspace, int B, int A, int h, int w, int s, int prec, int reps,
+                    void* stream, float* ms_out) {
+    Dims d; int rc;
+    if (!kernel || !packed || !workspace || !ms_out || reps < 1) return fail(LFT_ERR_ARG, "bad argument");
+    if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return prec == LFT_PREC_F32 ? kernel_time_impl<float>(kernel, packed, workspace, d, prec, reps, st, ms_out)
+                                : kernel_time_impl<bf16_t>(kernel, packed, workspace, d, prec, reps, st, ms_out);
+}
+
 int lft_bicubic_fwd(const float* lr, float* out, int B, int A, int h, int w, int s, void* stream) {
     Dims d; int rc;
     if (!lr || !out) return fail(LFT_ERR_ARG, "null pointer");
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
-    launch_assemble(lr, nullptr, out, B, A, h, w, s, 0, static_cast<hipStream_t>(stream));
-    LFT_LAUNCH_OK("k_assemble");
+    const dim3 grid((unsigned)((A * w * s + 255) / 256), (unsigned)(A * h * s), (unsigned)B);
+    k_bicubic<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(lr, out, B, A, h, w, s);
+    LFT_LAUNCH_OK("k_bicubic");
     return 0;
 }
 
@@ -559,19 +627,19 @@ int lft_debug_conv64(const void* packed, int which, int with_res, const void* in
     if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
     const PackedLayout L = packed_layout(d, prec);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int nimg = d.B * d.V, nwg = nimg * ((d.hw + 127) / 128);
+    const int nimg = d.B * d.V, nwg = nimg * ((d.hw + 32 * kNwConv - 1) / (32 * kNwConv));
     if (prec == LFT_PREC_F32) {
         const size_t lds = lds_conv64<float>(d.w) + extra_lds;
         if ((rc = allow_lds(k_conv64<float, false>, lds, "k_conv64"))) return rc;
         if ((rc = allow_lds(k_conv64<float, true>, lds, "k_conv64"))) return rc;
-        if (with_res) k_conv64<float, true><<<nwg, 256, lds, st>>>((const float*)in, (float*)out, (const float*)res, at<float>(packed, L.s_conv[which]), nimg, d.h, d.w);
-        else k_conv64<float, false><<<nwg, 256, lds, st>>>((const float*)in, (float*)out, nullptr, at<float>(packed, L.s_conv[which]), nimg, d.h, d.w);
+        if (with_res) k_conv64<float, true><<<nwg, 64 * kNwConv, lds, st>>>((const float*)in, (float*)out, (const float*)res, at<float>(packed, L.s_conv[which]), nimg, d.h, d.w);
+        else k_conv64<float, false><<<nwg, 64 * kNwConv, lds, st>>>((const float*)in, (float*)out, nullptr, at<float>(packed, L.s_conv[which]), nimg, d.h, d.w);
     } else {
         const size_t lds = lds_conv64<bf16_t>(d.w) + extra_lds;
         if ((rc = allow_lds(k_conv64<bf16_t, false>, lds, "k_conv64"))) return rc;
         if ((rc = allow_lds(k_conv64<bf16_t, true>, lds, "k_conv64"))) return rc;
-        if (with_res) k_conv64<bf16_t, true><<<nwg, 256, lds, st>>>((const bf16_t*)in, (bf16_t*)out, (const bf16_t*)res, at<bf16_t>(packed, L.s_conv[which]), nimg, d.h, d.w);
-        else k_conv64<bf16_t, false><<<nwg, 256, lds, st>>>((const bf16_t*)in, (bf16_t*)out, nullptr, at<bf16_t>(packed, L.s_conv[which]), nimg, d.h, d.w);
+        if (with_res) k_conv64<bf16_t, true><<<nwg, 64 * kNwConv, lds, st>>>((const bf16_t*)in, (bf16_t*)out, (const bf16_t*)res, at<bf16_t>(packed, L.s_conv[which]), nimg, d.h, d.w);
+        else k_conv64<bf16_t, false><<<nwg, 64 * kNwConv, lds, st>>>((const bf16_t*)in, (bf16_t*)out, nullptr, at<bf16_t>(packed, L.s_conv[which]), nimg, d.h, d.w);
     }
     LFT_LAUNCH_OK("k_conv64");
     return 0;
@@ -585,7 +653,7 @@ int lft_debug_read_stamps(unsigned long long* host_out, int n) {
     return 0;
 }
 int lft_debug_clear_stamps(void) {
-    static unsigned long long zeros[4096 * 16];
+    static unsigned long long zeros[4096 * 32];
     LFT_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_lft_stamps), zeros, sizeof(zeros)));
     return 0;
 }

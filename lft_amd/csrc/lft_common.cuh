@@ -34,13 +34,13 @@ typedef unsigned int raw16 __attribute__((ext_vector_type(4), may_alias));
 // Diagnostic build only (-DLFT_STAMPS): per-phase s_memtime stamps of wave 0 of every workgroup go to a
 // side buffer that no kernel reads (tools/stamp_report.py).  In the product build LFT_STAMP() is empty.
 #ifdef LFT_STAMPS
-__device__ unsigned long long g_lft_stamps[4096 * 16];
+__device__ unsigned long long g_lft_stamps[4096 * 32];    // 32 slots per workgroup: k_spa1 uses 0..15, k_spa2 16..31
 LFT_DEV void lft_stamp(int slot) {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (threadIdx.x == 0 && blockIdx.x < 4096) g_lft_stamps[blockIdx.x * 16 + slot] = t;
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_lft_stamps[blockIdx.x * 32 + slot] = t;
 }
 #define LFT_STAMP(slot) lft_stamp(slot)
 #else
@@ -193,14 +193,14 @@ LFT_DEV void wg_barrier_keep_vm() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barr
 //      wait reliably for LDS-DMA (k_up's loop had a bare "s_waitcnt lgkmcnt(0); s_barrier"), so it is explicit;
 //   2. executes the workgroup barrier: chunk c is published, chunk c-1 is retired by every wave;
 //   3. issues the DMA of chunk c+2 into the slot chunk c-1 just vacated.
-template <typename T, int CH>
+template <typename T, int CH, int NW = 4>       // NW: waves of the workgroup that share the ring
 struct WRing {
     static constexpr int NBUF = 3;
     static constexpr int FRAG_BYTES = 1024 * FragInfo<T>::PIECES;
     static constexpr int CHUNK_BYTES = CH * FRAG_BYTES;
     static constexpr int LDS_BYTES = NBUF * CHUNK_BYTES;
-    static constexpr int PIECES_PER_WAVE = CH * FragInfo<T>::PIECES / 4;
-    static_assert((CH * FragInfo<T>::PIECES) % 4 == 0, "chunk must split over 4 waves");
+    static constexpr int PIECES_PER_WAVE = CH * FragInfo<T>::PIECES / NW;
+    static_assert((CH * FragInfo<T>::PIECES) % NW == 0, "chunk must split over the workgroup's waves");
     static_assert(PIECES_PER_WAVE <= 12, "counted vmcnt immediates below cover up to 12 pieces per wave");
     const char* g;
     char* lds;
@@ -254,6 +254,63 @@ struct WRing {
     }
 };
 
+
+// Deep variant of the weight ring for kernels that can spare LDS: NBUF slots, DMA issued NBUF - 1 chunks ahead (the
+// L2 -> LDS latency under load is several chunk times; with the 3-slot ring every chunk boundary stalled on it).  The
+// slots may live in two separate LDS regions (slots >= split_slot are shifted by split_gap bytes), and the first
+// NBUF - 1 chunks are issued by the caller (issue(c)) as the regions become free -- see k_spa_b.  Same lock-step and
+// counted-vmcnt rules as WRing; VM operations the kernel issues in between only make the waits stricter.
+template <typename T, int CH, int NW, int NBUF>
+struct WRingDeep {
+    static constexpr int FRAG_BYTES = 1024 * FragInfo<T>::PIECES;
+    static constexpr int CHUNK_BYTES = CH * FRAG_BYTES;
+    static constexpr int PIECES_PER_WAVE = CH * FragInfo<T>::PIECES / NW;
+    static_assert((CH * FragInfo<T>::PIECES) % NW == 0, "chunk must split over the workgroup's waves");
+    static_assert(PIECES_PER_WAVE * (NBUF - 2) <= 63, "counted vmcnt immediate");
+    const char* g;
+    char* lds;
+    int lane, wave, pos, nfrag, split_slot, split_gap;
+    LFT_MEM void setup(const T* stream, char* lds_base, int total_frags, int split_slot_, int split_gap_) {
+        g = reinterpret_cast<const char*>(stream); lds = lds_base; nfrag = total_frags; pos = 0;
+        split_slot = split_slot_; split_gap = split_gap_;
+        lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    }
+    LFT_MEM char* slot(int c) const {
+        const int s = c % NBUF;
+        return lds + s * CHUNK_BYTES + (s >= split_slot ? split_gap : 0);
+    }
+    LFT_MEM void issue(int c) {                                         // every wave issues exactly PIECES_PER_WAVE pieces per existing chunk
+        if (c * CH >= nfrag) return;
+        const char* src = g + (size_t)c * CHUNK_BYTES;
+        char* dst = slot(c);
+        const int last = (nfrag - c * CH) * FragInfo<T>::PIECES - 1;
+#pragma unroll
+        for (int i = 0; i < PIECES_PER_WAVE; ++i) {
+            const int piece = min(wave * PIECES_PER_WAVE + i, last);
+            glds_piece(src + piece * 1024, dst + piece * 1024, lane);
+        }
+    }
+    LFT_MEM Frag<T> next() {
+        const int c = pos / CH, i = pos % CH;
+        if (i == 0) {
+            const int nchunk = (nfrag + CH - 1) / CH;
+            const int younger = max(0, min(NBUF - 2, nchunk - 1 - c));    // chunks c+1 .. c+NBUF-2 are in flight behind chunk c
+            wait_vmcnt(younger * PIECES_PER_WAVE);
+            wg_barrier_keep_vm();                                       // chunk c published, chunk c-1 retired by every wave
+            issue(c + NBUF - 1);                                        // into the slot chunk c-1 just vacated
+        }
+        ++pos;
+        return frag_from_pieces(slot(c) + i * FRAG_BYTES, lane, T());
+    }
+};
+template <int NT_OUT, int KS, typename T, int CH, int NW, int NBUF>
+LFT_DEV void linear_ring(WRingDeep<T, CH, NW, NBUF>& ring, const Frag<T> (&x)[KS], f32x16 (&y)[NT_OUT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT_OUT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) mma(ring.next(), x[ks], y[nt]);
+}
 
 // 8 consecutive channels of a token row in memory -> fragment in NATURAL k order (k = 8h + j);
 // used where an operand comes straight from HBM (attention output).  Branch-free: the caller passes an
@@ -533,6 +590,83 @@ LFT_DEV void load_tile(const T* __restrict__ gbase, int nvalid, int lane, f32x16
     }
 }
 
+// Tile I/O for a wave whose 32 tokens are NOT consecutive in memory: an 8 x 4 block of one view image (the windowed
+// attention's query block).  Row r of the tile = token (y0 + r / 8, x0 + r % 8): 8 consecutive tokens per image row.
+struct BlkRows {
+    int img_row_bytes;     // bytes from one image row to the next (w * bytes per token row)
+    int tok_bytes;         // bytes per token row
+    int nrow, ncol;        // rows (<= 4) and columns (<= 8) of the block that lie inside the image
+    LFT_MEM size_t off(int row) const { return (size_t)(row >> 3) * img_row_bytes + (size_t)(row & 7) * tok_bytes; }
+    LFT_MEM bool ok(int row) const { return (row >> 3) < nrow && (row & 7) < ncol; }
+};
+// As load_tile / store_tile, with the row -> address map given by `rm` (offsets relative to gbase, which must be a
+// readable address even when no row is valid).
+template <int NT, typename T, typename RM>
+LFT_DEV void load_tile_map(const T* __restrict__ gbase, const RM& rm, int lane, f32x16 (&a)[NT], char* scr) {
+    using IO = TileIO<NT, T>;
+    constexpr int NV = 16 * IO::P16 / 64;
+    const int r = lane & 31, hh = lane >> 5;
+    raw16 v[2][NV];                                                    // both passes' loads are issued up front: ONE memory round trip
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = i * 64 + lane, row = pass * 16 + idx / IO::P16, pc = idx % IO::P16;
+            const bool in = rm.ok(row);
+            const raw16 t = load_raw16(reinterpret_cast<const char*>(gbase) + (in ? rm.off(row) + pc * 16 : 0));
+            v[pass][i] = in ? t : raw16{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        wave_lds_fence();                                              // previous pass fully consumed
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = i * 64 + lane;
+            store_raw16(scr + (idx / IO::P16) * IO::ROWB + (idx % IO::P16) * 16, v[pass][i]);
+        }
+        wave_lds_fence();
+        if ((r >> 4) == pass) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 t = lds_load4(scr + (r & 15) * IO::ROWB + (32 * nt + 8 * g + 4 * hh) * (int)sizeof(T), T());
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[nt][4 * g + j] = t[j];
+                }
+        }
+    }
+}
+template <int NT, typename T, typename RM>
+LFT_DEV void store_tile_map(T* __restrict__ gbase, const RM& rm, int lane, const f32x16 (&a)[NT], char* scr) {
+    using IO = TileIO<NT, T>;
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        wave_lds_fence();                                              // previous pass fully read
+        if ((r >> 4) == pass) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    lds_store4(scr + (r & 15) * IO::ROWB + (32 * nt + 8 * g + 4 * hh) * (int)sizeof(T),
+                               f32x4{a[nt][4 * g], a[nt][4 * g + 1], a[nt][4 * g + 2], a[nt][4 * g + 3]}, T());
+        }
+        wave_lds_fence();
+        raw16 v[16 * IO::P16 / 64];
+#pragma unroll
+        for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
+            const int idx = i * 64 + lane;
+            v[i] = load_raw16(scr + (idx / IO::P16) * IO::ROWB + (idx % IO::P16) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
+            const int idx = i * 64 + lane, row = pass * 16 + idx / IO::P16, pc = idx % IO::P16;
+            if (rm.ok(row)) store_raw16(reinterpret_cast<char*>(gbase) + rm.off(row) + pc * 16, v[i]);
+        }
+    }
+}
+
 // Load a tile of rows as NATURAL-order B fragments (k = 16 ks + 8 h + j), e.g. the attention output.
 template <int KS, typename T>
 LFT_DEV void load_tile_frags(const T* __restrict__ gbase, int nvalid, int lane, Frag<T> (&f)[KS], char* scr) {
@@ -639,7 +773,7 @@ LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* gamma, const float* bet
 // store only after the kernel's one big vmcnt wait (a load -> ds_write pair in the prologue costs a full memory
 // round trip there, vmcnt being in-order).  n % 4 == 0, n <= 1024.  The caller's barrier publishes the store.
 LFT_DEV raw16 params_load(const float* __restrict__ src, int n) {
-    const int i = min((int)threadIdx.x * 4, n - 4);
+    const int i = min((int)threadIdx.x * 4, n - 4);     // threads beyond n/4 re-read the last piece and store nothing
     return load_raw16(reinterpret_cast<const char*>(src + i));
 }
 LFT_DEV void params_store(float* lds_dst, int n, raw16 v) {
@@ -658,8 +792,8 @@ LFT_DEV void acc_frags(const f32x16 (&a)[NT], Frag<T> (&f)[2 * NT]) {
 }
 
 // Same, weights taken in stream order from the workgroup's LDS ring.
-template <int NT_OUT, int KS, typename T, int CH>
-LFT_DEV void linear_ring(WRing<T, CH>& ring, const Frag<T> (&x)[KS], f32x16 (&y)[NT_OUT]) {
+template <int NT_OUT, int KS, typename T, int CH, int NW>
+LFT_DEV void linear_ring(WRing<T, CH, NW>& ring, const Frag<T> (&x)[KS], f32x16 (&y)[NT_OUT]) {
 #pragma unroll
     for (int nt = 0; nt < NT_OUT; ++nt)
 #pragma unroll

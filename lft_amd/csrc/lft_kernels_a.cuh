@@ -133,24 +133,24 @@ __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, con
 //    them, as it does at the left/right image border (per-view zero padding, reference LFT.py:24,27,167).
 //  * weights: the fragment stream ((tap*4 + ks) * NT + nt) arrives through the workgroup's LDS ring.
 // ------------------------------------------------------------------------------------------
-template <typename T> struct ConvIn {
+template <typename T, int NW = 4> struct ConvIn {     // NW waves x 32 tokens per workgroup tile
     static constexpr int ROW_BYTES = 64 * (int)sizeof(T);
     static constexpr int PPR = ROW_BYTES / 16;                       // 16-byte pieces per token row (8 / 16)
     static constexpr int SLOTS_PER_DMA = 1024 / ROW_BYTES;           // token rows per 1 KiB LDS-DMA piece (8 / 4)
-    static __host__ __device__ int slots(int w) { return 130 + 2 * w; }
+    static __host__ __device__ int slots(int w) { return 32 * NW + 2 + 2 * w; }
     static __host__ __device__ int dma_pieces(int w) { return (slots(w) + SLOTS_PER_DMA - 1) / SLOTS_PER_DMA; }
     static __host__ __device__ int bytes(int w) { return dma_pieces(w) * 1024; }
     static __device__ __forceinline__ int swz(int slot) { return sizeof(T) == 2 ? ((slot >> 1) & 7) : (slot & 15); }
 };
 
 // Issues the DMA only; the caller waits (vmcnt) and publishes (barrier) before the first read.
-template <typename T>
+template <typename T, int NW = 4>
 LFT_DEV void stage_conv_input(const T* __restrict__ img, int p0, int hw, int w, char* lds_in) {
-    using CI = ConvIn<T>;
+    using CI = ConvIn<T, NW>;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int npieces = CI::dma_pieces(w);
-    for (int piece = wave; piece < npieces; piece += 4) {
+    for (int piece = wave; piece < npieces; piece += NW) {
         const int slot = piece * CI::SLOTS_PER_DMA + lane / CI::PPR, cpos = lane % CI::PPR;
         const int q = min(max(p0 - w - 1 + slot, 0), hw - 1);                       // clamped: out-of-image rows are masked at use
         const char* src = reinterpret_cast<const char*>(img) + ((size_t)q * CI::ROW_BYTES + ((cpos ^ CI::swz(slot)) * 16));
@@ -161,10 +161,10 @@ LFT_DEV void stage_conv_input(const T* __restrict__ img, int p0, int hw, int w, 
 LFT_DEV void wait_staged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // own DMA pieces and early loads landed
 
 // tl = token index inside the workgroup tile (0..127); (y, x) its image coordinates.
-template <int NT, typename T, int CH>
+template <int NT, typename T, int CH, int NW>
 LFT_DEV void conv3x3_tile(const char* lds_in, int tl, int y, int x, bool ok, int h, int w, int hh,
-                          WRing<T, CH>& ring, f32x16 (&acc)[NT]) {
-    using CI = ConvIn<T>;
+                          WRing<T, CH, NW>& ring, f32x16 (&acc)[NT]) {
+    using CI = ConvIn<T, NW>;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -190,29 +190,36 @@ LFT_DEV void conv3x3_tile(const char* lds_in, int tl, int y, int x, bool ok, int
 }
 
 // conv_init[i]: 64 -> 64 + LeakyReLU(0.2); the last one adds conv_init0's output (reference LFT.py:26-33,66).
-#ifndef LFT_CONV64_CHUNK
-#define LFT_CONV64_CHUNK 12
+// A workgroup = NW waves x 32 consecutive tokens of one view image; all its waves share one weight ring, so the
+// packed weights are streamed into the CU once per 32*NW tokens.
+#ifndef LFT_NW_CONV
+#define LFT_NW_CONV 4
 #endif
-constexpr int kConv64Chunk = LFT_CONV64_CHUNK;   // 72 fragments = 6 chunks; 3-slot ring = 36 KiB (bf16) so two workgroups share a CU
-template <typename T, bool RES>
-__global__ __launch_bounds__(256) void k_conv64(const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ res,
-                                                const T* __restrict__ wstream, int nimg, int h, int w) {
+constexpr int kNwConv = LFT_NW_CONV;
+#ifndef LFT_CONV64_CHUNK
+#define LFT_CONV64_CHUNK (LFT_NW_CONV == 4 ? 12 : LFT_NW_CONV)
+#endif
+constexpr int kConv64Chunk = LFT_CONV64_CHUNK;   // 72 fragments; NW = 4: 6 chunks of 12, 3-slot ring = 36 KiB (bf16) so two workgroups share a CU
+template <typename T, bool RES, int NW = kNwConv>
+__global__ __launch_bounds__(64 * NW) void k_conv64(const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ res,
+                                                   const T* __restrict__ wstream, int nimg, int h, int w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TT = 32 * NW;                                       // tokens per workgroup tile
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5, wave = threadIdx.x >> 6;
-    const int hw = h * w, tpi = (hw + 127) >> 7;
+    const int hw = h * w, tpi = (hw + TT - 1) / TT;
     const int bid = xcd_tile(blockIdx.x, gridDim.x);                  // neighbouring tiles (shared halo rows) on one XCD
-    const int im = bid / tpi, p0 = (bid % tpi) * 128;
+    const int im = bid / tpi, p0 = (bid % tpi) * TT;
     const int tl = wave * 32 + r, p = p0 + tl;
     const bool ok = p < hw;
     const int t0 = p0 + wave * 32, nvalid = max(0, min(32, hw - t0));                 // this wave's 32 consecutive tokens
     const size_t tile_off = ((size_t)im * hw + min(t0, hw - 1)) * 64;
-    char* lds_in = smem + WRing<T, kConv64Chunk>::LDS_BYTES;
-    char* scr = lds_in + ConvIn<T>::bytes(w) + wave * TileIO<2, T>::BYTES;            // wave-private tile I/O scratch
+    char* lds_in = smem + WRing<T, kConv64Chunk, NW>::LDS_BYTES;
+    char* scr = lds_in + ConvIn<T, NW>::bytes(w) + wave * TileIO<2, T>::BYTES;        // wave-private tile I/O scratch
     f32x16 rr[2];
     if (RES) load_tile<2, T>(res + tile_off, nvalid, lane, rr, scr);                  // first: its latency hides under the tile
-    WRing<T, kConv64Chunk> ring;
+    WRing<T, kConv64Chunk, NW> ring;
     ring.init(wstream, smem, 72);
-    stage_conv_input<T>(in + (size_t)im * hw * 64, p0, hw, w, lds_in);
+    stage_conv_input<T, NW>(in + (size_t)im * hw * 64, p0, hw, w, lds_in);
     wait_staged();
     __syncthreads();                                                                 // ... and everybody else's
     f32x16 acc[2];
@@ -269,10 +276,13 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
         }
     }
     float* lds_ln = reinterpret_cast<float*>(smem + 64 * FB);
+    LFT_STAMP(0);
     const raw16 lnv = params_load(ln, 256);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own LDS-DMA pieces landed, then publish (see WRing::next)
     params_store(lds_ln, 256, lnv);
     __syncthreads();
+    LFT_STAMP(1);
+    [[maybe_unused]] int stamp_it = 0;                                     // diagnostic build: second tile's stamps go to slots 7..11
     const bool ok = r < V;
     f32x16 negmask;                                                                       // 0 for key rows < V, -inf beyond
 #pragma unroll
@@ -286,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
 
         f32x16 x[2], n[2];
         load_tile<2, T>(X + off0, V, lane, x, scr, vstride);                              // rows = views: 8 lanes x 16 B per row
+        LFT_STAMP(2 + 5 * stamp_it);
         {
             typename RawPiece<float>::type pr[8];
             load_lane_major_raw<2, float>(pe, lane, pr);
@@ -307,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) mma(xf[ks], frag_from_pieces(smem + (16 + nt * 4 + ks) * FB, lane, T()), v[nt]);
 
+        LFT_STAMP(3 + 5 * stamp_it);
 #pragma unroll
         for (int hd = 0; hd < 8; ++hd) {
             const int nt = hd >> 2, s = (hd >> 1) & 1, half = hd & 1;
@@ -329,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
             for (int i = 0; i < 4; ++i) o[nt][4 * (hd & 3) + i] *= inv;
         }
 
+        LFT_STAMP(4 + 5 * stamp_it);
         Frag<T> of[4];
         acc_frags<2, T>(o, of);
         linear_lds<2, 4, T>(smem, 24, lane, of, x);              // t = x + O Wo^T
@@ -346,7 +359,10 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
             for (int i = 0; i < 16; ++i) hid[nt][i] = fmaxf(hid[nt][i], 0.0f);
         acc_frags<4, T>(hid, hf);
         linear_lds<2, 8, T>(smem, 48, lane, hf, x);
+        LFT_STAMP(5 + 5 * stamp_it);
         store_tile<2, T>(Y + off0, V, lane, x, scr, vstride);
+        LFT_STAMP(6 + 5 * stamp_it);
+        stamp_it = 1;
     }
 }
 

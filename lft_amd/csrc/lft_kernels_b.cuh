@@ -23,29 +23,41 @@ constexpr int kUpChunk = LFT_UP_CHUNK;    // k_up uses few registers: a smaller 
 #define LFT_SPA_OCC 2
 #endif
 constexpr int kSpaChunk = LFT_SPA_CHUNK;   // fragments per ring chunk: one conv tap (4 k-steps x 4 row tiles), half an in_proj matrix
-template <typename T, bool PE_ONLY, int CH = kSpaChunk, bool TOKLM = false>   // TOKLM: the token tile goes to k_spa2 in lane-major tile format
-__global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
+// Waves per workgroup (x 32 tokens each).  All waves of a workgroup share one weight ring: the packed weights are
+// streamed into the CU once per 32*NW tokens, and one ring barrier serves NW waves.
+#ifndef LFT_NW_SPA1
+#define LFT_NW_SPA1 4
+#endif
+#ifndef LFT_NW_SPA2
+#define LFT_NW_SPA2 4
+#endif
+#ifndef LFT_NW_UP
+#define LFT_NW_UP 4
+#endif
+constexpr int kNwSpa1 = LFT_NW_SPA1, kNwSpa2 = LFT_NW_SPA2, kNwUp = LFT_NW_UP;
+template <typename T, bool PE_ONLY, int CH = kSpaChunk, bool TOKLM = false, int NW = kNwSpa1>   // TOKLM: the token tile goes to k_spa2 in lane-major tile format
+__global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const T* __restrict__ petok,
                                               T* __restrict__ TOK, T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vv,
                                               T* __restrict__ pe_out, int nimg, int h, int w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5, wave = threadIdx.x >> 6;
-    const int hw = h * w, tpi = (hw + 127) >> 7;
+    constexpr int TT = 32 * NW;                                       // tokens per workgroup tile
+    const int hw = h * w, tpi = (hw + TT - 1) / TT;
     const int bid = xcd_tile(blockIdx.x, gridDim.x);                  // neighbouring tiles (shared halo rows) on one XCD
-    const int im = bid / tpi, p0 = (bid % tpi) * 128;
+    const int im = bid / tpi, p0 = (bid % tpi) * TT;
     const int tl = wave * 32 + r, p = p0 + tl;
     const bool ok = p < hw;
-    const int pc = min(p, hw - 1);
     LFT_STAMP(0);
     typename RawPiece<T>::type pe_raw[16];                                    // position tokens of this lane's token, kept packed
     if (!PE_ONLY) load_lane_major_raw<4, T>(petok + (size_t)((p0 >> 5) + wave) * 4096, lane, pe_raw);   // early, 8 coalesced loads
-    char* lds_in = smem + WRing<T, CH>::LDS_BYTES;
-    float* lds_ln = reinterpret_cast<float*>(lds_in + ConvIn<T>::bytes(w));
+    char* lds_in = smem + WRing<T, CH, NW>::LDS_BYTES;
+    float* lds_ln = reinterpret_cast<float*>(lds_in + max(ConvIn<T, NW>::bytes(w), NW * TileIO<4, T>::BYTES));   // the tile I/O scratch aliases the conv input
     raw16 lnv = raw16{0u, 0u, 0u, 0u};
     if (!PE_ONLY) lnv = params_load(ln, 256);                         // norm.{weight,bias}; ln is null in the pack-time PE_ONLY launch
-    WRing<T, CH> ring;
-    ring.init(ws, smem, PE_ONLY ? 144 : 240, p0 + 128 <= hw);
-    stage_conv_input<T>(X + (size_t)im * hw * 64, p0, hw, w, lds_in);
+    WRing<T, CH, NW> ring;
+    ring.init(ws, smem, PE_ONLY ? 144 : 240, p0 + TT <= hw);
+    stage_conv_input<T, NW>(X + (size_t)im * hw * 64, p0, hw, w, lds_in);
     LFT_STAMP(12);
     wait_staged();
     LFT_STAMP(13);
@@ -66,7 +78,7 @@ __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa1(const T* __restrict__
     const int t0 = p0 + wave * 32, nvalid = max(0, min(32, hw - t0));
     const size_t tile_off = ((size_t)im * hw + min(t0, hw - 1)) * 128;
     char* scr = lds_in + wave * TileIO<4, T>::BYTES;
-    if constexpr (TOKLM) ring.note_vm(store_tile_lm<4, T>(TOK + ((size_t)im * hw + t0) * 128, lane, t));   // hw % 128 == 0: every tile is full
+    if constexpr (TOKLM) ring.note_vm(store_tile_lm<4, T>(TOK + ((size_t)im * hw + t0) * 128, lane, t));   // hw % (32 NW) == 0: every tile is full
     else ring.note_vm(store_tile<4, T>(TOK + tile_off, nvalid, lane, t, scr));
     LFT_STAMP(4);
     Frag<T> nf[8];
@@ -105,219 +117,127 @@ __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa1(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// SpaTrans windowed attention core (reference LFT.py:147-162 mask + :183-187 attention): keys = clamped 5x5 window around
+// SpaTrans windowed attention (reference LFT.py:147-162 mask + :183-187 attention): keys = clamped 5x5 window around
 // the query.  The reference bounds the window columns by min(h, x+3) (LFT.py:155, "h" where "w" is meant) and slicing
 // clips at w; reproduced as-is: for h < w some queries see no key at all and get a zero attention output (what the
 // reference gives under torch >= 2.5).  Q is pre-scaled by scale*log2(e); softmax uses exp2.
+// bf16: fused with the per-token tail in k_spa_b below; fp32: k_win_attn_lds (lft_train.cuh) followed by k_spa2.
+// Geometry of the MFMA attention: a workgroup = a 4 x 32 tile of queries of one view image, wave c owning the 8 x 4
+// block of columns 8c .. 8c+7 (32 queries on its 32 MFMA columns).  The block's clamped 5x5 windows live inside a
+// 12 x 8 neighbourhood = 96 keys = three 32-key tiles; the workgroup's keys are the 8 x 36 halo tile around it.
 // ------------------------------------------------------------------------------------------
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-LFT_DEV void load_pairs16(const bf16_t* p, bf16x2 (&o)[8]) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p), b = *reinterpret_cast<const bf16x8*>(p + 8);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { o[i] = bf16x2{a[2 * i], a[2 * i + 1]}; o[4 + i] = bf16x2{b[2 * i], b[2 * i + 1]}; }
-}
-// LDS-tiled bf16 windowed attention on the VALU (v_dot2c): superseded by the MFMA kernel below, kept for A/B builds
-// (-DLFT_ATT_VALU).  The fp32 path uses the LDS-tiled kernel of lft_train.cuh (k_win_attn_lds<0, true>).
-// A 512-thread workgroup owns a 4 x 32 tile of queries of one view image and 4 of the 8 heads (64 channels).
-// The (4+4) x (32+4) halo tile of K -- then of V, re-using the same 41 KiB -- is staged once into LDS (every key is
-// used by up to 25 queries x 4 heads), token rows padded to 144 B so the 16-byte reads of a half-wave (32 different
-// query columns) fall on distinct banks.  wave = (head, 2 query rows), lane = (row parity, column).
-#ifndef LFT_ATT_TY
-#define LFT_ATT_TY 4
-#endif
-constexpr int kAttTY = LFT_ATT_TY, kAttTX = 32, kAttHR = kAttTY + 4, kAttHC = kAttTX + 4, kAttRow = 144;
-constexpr int kAttThreads = kAttTY * kAttTX * 4;      // one thread per (query, head) for 4 heads
-constexpr int kAttLds = kAttHR * kAttHC * kAttRow;
-LFT_DEV void att_stage(const bf16_t* __restrict__ src, char* lds, long long img_tok0, int ty, int tx, int hg, int h, int w) {
-    constexpr int N = kAttHR * kAttHC * 8, ITER = (N + kAttThreads - 1) / kAttThreads;   // 16-byte pieces of the halo tile
-    raw16 v[ITER];
-#pragma unroll
-    for (int u = 0; u < ITER; ++u) {                                       // all loads first (branch-free), then all stores
-        const int idx = min((int)threadIdx.x + kAttThreads * u, N - 1);
-        const int slot = idx >> 3, piece = idx & 7;
-        const int gy = ty * kAttTY - 2 + slot / kAttHC, gx = tx * kAttTX - 2 + slot % kAttHC;
-        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
-        const long long t = in ? img_tok0 + gy * w + gx : img_tok0;
-        const raw16 r = load_raw16(reinterpret_cast<const char*>(src + t * 128 + hg * 64) + piece * 16);
-        v[u] = in ? r : raw16{0u, 0u, 0u, 0u};
-    }
-#pragma unroll
-    for (int u = 0; u < ITER; ++u) {
-        const int idx = (int)threadIdx.x + kAttThreads * u;
-        if (idx < N) store_raw16(lds + (idx >> 3) * kAttRow + (idx & 7) * 16, v[u]);
-    }
-}
-LFT_DEV void lds_pairs16(const char* p, bf16x2 (&o)[8]) {
-    const bf16x8 a = __builtin_bit_cast(bf16x8, load_raw16(p)), b = __builtin_bit_cast(bf16x8, load_raw16(p + 16));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { o[i] = bf16x2{a[2 * i], a[2 * i + 1]}; o[4 + i] = bf16x2{b[2 * i], b[2 * i + 1]}; }
-}
-__global__ __launch_bounds__(kAttThreads) void k_spa_attn_lds(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                      const bf16_t* __restrict__ Vv, bf16_t* __restrict__ O, int h, int w) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tiles_x = (w + kAttTX - 1) / kAttTX, tiles_y = (h + kAttTY - 1) / kAttTY;
-    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, im = blockIdx.x / (tiles_x * tiles_y);
-    const int hg = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int hl = wave & 3, qrow = (wave >> 2) * 2 + (lane >> 5), qcol = lane & 31;
-    const int y = ty * kAttTY + qrow, x = tx * kAttTX + qcol;
-    const bool valid = y < h && x < w;
-    const long long img0 = (long long)im * h * w;
-    const long long tok = img0 + min(y, h - 1) * w + min(x, w - 1);
-    const int y0 = max(0, y - 2), y1 = min(h, y + 3), x0 = max(0, x - 2), x1 = min(min(h, x + 3), w);   // reference LFT.py:155 (sic)
-#ifdef LFT_ATT_FMA
-    // Experiment (tools/ab_build.py fma:-DLFT_ATT_FMA): unpack bf16 by shift / mask and use plain fp32 FMAs.
-    // Measured 102 us vs 64 us for the v_dot2c_f32_bf16 form below: the kernel is VALU-issue-bound, fewer instructions win.
-    float q[16];
-    {
-        bf16x2 qp[8];
-        load_pairs16(Q + tok * 128 + hg * 64 + hl * 16, qp);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { q[2 * c] = (float)qp[c][0]; q[2 * c + 1] = (float)qp[c][1]; }
-    }
-    att_stage(K, smem, img0, ty, tx, hg, h, w);
-    __syncthreads();
-    float s[25];
-    float m = -INFINITY;
-    const char* base = smem + (qrow * kAttHC + qcol) * kAttRow + hl * 32;
-#pragma unroll
-    for (int t = 0; t < 25; ++t) {
-        const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
-        const raw16 k0 = load_raw16(base + ((t / 5) * kAttHC + t % 5) * kAttRow), k1 = load_raw16(base + ((t / 5) * kAttHC + t % 5) * kAttRow + 16);
-        float d = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            d += q[2 * c] * __builtin_bit_cast(float, k0[c] << 16) + q[2 * c + 1] * __builtin_bit_cast(float, k0[c] & 0xffff0000u);
-            d += q[8 + 2 * c] * __builtin_bit_cast(float, k1[c] << 16) + q[8 + 2 * c + 1] * __builtin_bit_cast(float, k1[c] & 0xffff0000u);
-        }
-        s[t] = (ky >= y0 && ky < y1 && kx >= x0 && kx < x1) ? d : -INFINITY;
-        m = fmaxf(m, s[t]);
-    }
-    __syncthreads();                       // everyone is done with K
-    att_stage(Vv, smem, img0, ty, tx, hg, h, w);
-    __syncthreads();
-    float sum = 0.0f, o[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) o[c] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 25; ++t) {
-        float pr = (s[t] != -INFINITY) ? fast_exp2(s[t] - m) : 0.0f;
-        sum += pr;
-        pr = (float)(bf16_t)pr;            // P rounded to bf16, as an MFMA operand would be
-        const raw16 v0 = load_raw16(base + ((t / 5) * kAttHC + t % 5) * kAttRow), v1 = load_raw16(base + ((t / 5) * kAttHC + t % 5) * kAttRow + 16);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            o[2 * c] += pr * __builtin_bit_cast(float, v0[c] << 16);
-            o[2 * c + 1] += pr * __builtin_bit_cast(float, v0[c] & 0xffff0000u);
-            o[8 + 2 * c] += pr * __builtin_bit_cast(float, v1[c] << 16);
-            o[8 + 2 * c + 1] += pr * __builtin_bit_cast(float, v1[c] & 0xffff0000u);
-        }
-    }
-#else
-    bf16x2 q[8], kv[8];
-    load_pairs16(Q + tok * 128 + hg * 64 + hl * 16, q);
-    att_stage(K, smem, img0, ty, tx, hg, h, w);
-    __syncthreads();
-    float s[25];
-    float m = -INFINITY;
-    const char* base = smem + (qrow * kAttHC + qcol) * kAttRow + hl * 32;
-#pragma unroll
-    for (int t = 0; t < 25; ++t) {
-        const int ky = y - 2 + t / 5, kx = x - 2 + t % 5;
-        lds_pairs16(base + ((t / 5) * kAttHC + t % 5) * kAttRow, kv);
-        float d = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) d = __builtin_amdgcn_fdot2_f32_bf16(q[c], kv[c], d, false);
-        s[t] = (ky >= y0 && ky < y1 && kx >= x0 && kx < x1) ? d : -INFINITY;
-        m = fmaxf(m, s[t]);
-    }
-    __syncthreads();                       // everyone is done with K
-    att_stage(Vv, smem, img0, ty, tx, hg, h, w);
-    __syncthreads();
-    float sum = 0.0f, o[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) o[c] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 25; ++t) {
-        const float pr = (s[t] != -INFINITY) ? fast_exp2(s[t] - m) : 0.0f;
-        sum += pr;
-        const bf16_t pb = (bf16_t)pr;
-        const bf16x2 p0 = bf16x2{pb, (bf16_t)0.0f}, p1 = bf16x2{(bf16_t)0.0f, pb};
-        lds_pairs16(base + ((t / 5) * kAttHC + t % 5) * kAttRow, kv);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            o[2 * c] = __builtin_amdgcn_fdot2_f32_bf16(p0, kv[c], o[2 * c], false);
-            o[2 * c + 1] = __builtin_amdgcn_fdot2_f32_bf16(p1, kv[c], o[2 * c + 1], false);
-        }
-    }
-#endif
-    if (!valid) return;
-    const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;      // empty window (h < w quirk) -> 0, see the generic kernel
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-        store4(O + tok * 128 + hg * 64 + hl * 16 + 4 * g, f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv});
-}
-
-// ------------------------------------------------------------------------------------------
-// MFMA windowed attention (bf16 production path; same maths as the two kernels above).
-// A workgroup = a 4 x 32 tile of queries of one view image; wave c owns the 8 x 4 block of columns 8c..8c+7
-// (32 queries on its 32 MFMA columns).  The block's clamped 5x5 windows live inside a 12 x 8 neighbourhood =
-// 96 keys = three 32-key tiles.  Per pair of heads (32 channels) the K and V halo tiles (8 x 36 tokens) are
-// staged in LDS once for the four waves, then per head
-//   S^T[key, q]  = K_tile . Q^T          3 MFMAs (head_dim 16 = exactly one k-step); the accumulator is
-//                                        initialised with a 0 / -inf bias that encodes window, image border
-//                                        and the reference's min(h, x+3) column clamp (LFT.py:155)
-//   softmax over the 96 rows             in registers + one lane^32 exchange (raw v_exp_f32)
-//   O^T[d, q]   += V^T_tile . P^T        6 MFMAs; V^T operand fragments come straight out of the row-major LDS
-//                                        tile through ds_read_b64_tr_b16 (hardware transposing read)
-// i.e. the dot products run on the matrix pipe and the VALU only does the softmax: about half the VALU
-// instructions per query of the dot2c kernel above, which was VALU-issue-bound.
-// ------------------------------------------------------------------------------------------
-constexpr int kAmRow = 80;                                   // 32 channels (2 heads) x bf16 + 16 B pad per staged token
-constexpr int kAmSlots = kAttHR * kAttHC;                    // 8 x 36 halo tokens (kAttTY = 4, kAttTX = 32)
-constexpr int kAmLds = 2 * kAmSlots * kAmRow;                // K tile + V tile
-static_assert(LFT_ATT_TY == 4, "k_spa_attn_mfma is written for 4-row tiles");
+constexpr int kAttTY = 4, kAttTX = 32, kAttHR = kAttTY + 4, kAttHC = kAttTX + 4;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-// Per-thread staging plan of the 8 x 36 x (2 heads) halo tile: which global token / LDS slot each of the thread's
-// 16-byte pieces touches.  Independent of the head pair, so it is computed once per workgroup tile.
-struct AmPlan {
-    static constexpr int N = kAmSlots * 4, ITER = (N + 255) / 256;      // 16-byte pieces: 4 per token
-    long long gofs[ITER];                                               // element offset of the piece in Q/K/V ([tok][128]), head pair 0
-    int lofs[ITER];                                                     // byte offset in the LDS tile (or -1: no store)
-    unsigned inmask;                                                    // bit u: the token exists in the image
-};
-LFT_DEV void am_plan(AmPlan& p, long long img0, int y0, int x0, int h, int w) {
-    p.inmask = 0;
+// ------------------------------------------------------------------------------------------
+// SpaTrans part 2 (reference LFT.py:187-189, 171-174): per 32-token tile
+//   t  = tok + O Wo^T ;  t2 = t + W2 relu(W1 LN'(t)) ;  y = Wl t2  (Conv3d 1x1x1 128->64)  [+ global skip, LFT.py:76]
+// FFN hidden width 256 is processed in four 64-wide chunks so the hidden activations never leave registers.
+// Stream: Wo[4x8, natural k] {W1c[2x8] W2c[4x4]} x4  Wl[2x8]  (176 fragments).
+// ------------------------------------------------------------------------------------------
+template <typename T, bool SKIP, bool TOKLM = false, bool YLM = false, int NW = kNwSpa2>   // YLM: output tile in lane-major form (consumer: k_up)
+__global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa2(const T* __restrict__ TOK, const T* __restrict__ O, const T* __restrict__ ws,
+                                              const float* __restrict__ ln, const T* __restrict__ skip, T* __restrict__ Y,
+                                              long long ntok) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const long long t0 = ((long long)blockIdx.x * NW + wave) * 32;                    // this wave's 32 consecutive tokens
+    const int nvalid = (int)max(0LL, min(32LL, ntok - t0));
+    const long long tb = min(t0, ntok - 1);
+    char* scr = smem + WRing<T, kSpaChunk, NW>::LDS_BYTES + 1024 + wave * TileIO<4, T>::BYTES;   // wave-private tile I/O scratch
+    WRing<T, kSpaChunk, NW> ring;
+    LFT_STAMP(16);
+    ring.init(ws, smem, 176);                 // first: the weight DMA is in flight while the activation tiles are fetched
+    f32x16 t[4], n[4];
+    if constexpr (TOKLM) load_tile_lm<4, T>(TOK + tb * 128, lane, t);       // written by k_spa1 in the same 32-token tiling
+    else load_tile<4, T>(TOK + tb * 128, nvalid, lane, t, scr);
+    Frag<T> f[8];
+    load_tile_frags<8, T>(O + tb * 128, nvalid, lane, f, scr);
+    f32x16 sk[2];
+    if (SKIP) load_tile<2, T>(skip + tb * 64, nvalid, lane, sk, scr);
+    float* lds_ln = reinterpret_cast<float*>(smem + WRing<T, kSpaChunk, NW>::LDS_BYTES);
+    params_store(lds_ln, 256, params_load(ln + 256, 256));            // feed_forward.0.{weight,bias}; the tile loads above were waited for anyway; published by the first ring barrier
+    LFT_STAMP(17);
+    linear_ring<4, 8, T>(ring, f, t);
+    LFT_STAMP(18);
 #pragma unroll
-    for (int u = 0; u < AmPlan::ITER; ++u) {
-        const int raw = (int)threadIdx.x + 256 * u, idx = min(raw, AmPlan::N - 1);
-        const int slot = idx >> 2, piece = idx & 3;
-        const int gy = y0 - 2 + slot / kAttHC, gx = x0 - 2 + slot % kAttHC;
-        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
-        p.gofs[u] = (in ? img0 + gy * w + gx : img0) * 128 + piece * 8;
-        p.lofs[u] = raw < AmPlan::N ? slot * kAmRow + piece * 16 : -1;
-        p.inmask |= (in ? 1u : 0u) << u;
+    for (int nt = 0; nt < 4; ++nt) n[nt] = t[nt];
+    layernorm_acc<4>(n, lds_ln, lds_ln + 128, hh);
+    acc_frags<4, T>(n, f);
+    LFT_STAMP(19);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        f32x16 hid[2];
+        zero_acc<2>(hid);
+        linear_ring<2, 8, T>(ring, f, hid);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hid[nt][i] = fmaxf(hid[nt][i], 0.0f);
+        Frag<T> hf[4];
+        acc_frags<2, T>(hid, hf);
+        linear_ring<4, 4, T>(ring, hf, t);
     }
-}
-LFT_DEV void am_load(const AmPlan& p, const bf16_t* __restrict__ src, int hg, raw16 (&v)[AmPlan::ITER]) {
+    LFT_STAMP(20);
+    acc_frags<4, T>(t, f);
+    f32x16 y[2];
+    zero_acc<2>(y);
+    linear_ring<2, 8, T>(ring, f, y);
+    if (SKIP) {
 #pragma unroll
-    for (int u = 0; u < AmPlan::ITER; ++u) {
-        const raw16 r = load_raw16(reinterpret_cast<const char*>(src + p.gofs[u] + hg * 32));
-        v[u] = ((p.inmask >> u) & 1u) ? r : raw16{0u, 0u, 0u, 0u};
+        for (int nt = 0; nt < 2; ++nt) y[nt] += sk[nt];
     }
-}
-LFT_DEV void am_store(const AmPlan& p, char* lds, const raw16 (&v)[AmPlan::ITER]) {
-#pragma unroll
-    for (int u = 0; u < AmPlan::ITER; ++u)
-        if (p.lofs[u] >= 0) store_raw16(lds + p.lofs[u], v[u]);
+    LFT_STAMP(21);
+    if constexpr (YLM) store_tile_lm<2, T>(Y + tb * 64, lane, y);
+    else store_tile<2, T>(Y + tb * 64, nvalid, lane, y, scr);
+    LFT_STAMP(22);
 }
 
-__global__ __launch_bounds__(256, 2) void k_spa_attn_mfma(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                          const bf16_t* __restrict__ Vv, bf16_t* __restrict__ O, int h, int w) {
+// ------------------------------------------------------------------------------------------
+// SpaTrans part B, bf16 (reference LFT.py:183-189, 171-174): windowed attention AND the per-token tail in one kernel.
+// The O^T accumulators of the MFMA attention (channel on the register, query on the lane) are -- converted to bf16 --
+// exactly the B operand of out_proj in "acc order", so the attention output never goes to memory (k_spa_attn_mfma wrote
+// 26 MB per launch at B = 4 and k_spa2 read them back through an LDS transposition).  A workgroup = a 4 x 32 tile of
+// queries of one view image, wave c owning the 8 x 4 block of columns 8c .. 8c+7, as in k_spa_attn_mfma; the same 32
+// tokens then go through  t = tok + O Wo^T ; t += W2 relu(W1 LN'(t)) ; y = Wl t (+ global skip)  as in k_spa2.
+// Stream: Wo[4x8, ACC order] {W1c[2x8] W2c[4x4]} x4  Wl[2x8]  (176 fragments) through an 8-fragment-chunk ring, so that
+// ring + K/V halo tiles stay below 80 KiB and two workgroups share a CU.  TOK / skip / Y are row-major [token][channel];
+// a wave's 8 x 4 block is four runs of 8 consecutive tokens (BlkRows).
+// ------------------------------------------------------------------------------------------
+#ifndef LFT_SPAB_TWOPASS
+#define LFT_SPAB_TWOPASS 0
+#endif
+constexpr int kSpaBChunk = 8, kSpaBSlots = 6;
+constexpr int kAdTile = kAttHR * kAttHC * 64;                 // one tensor's halo tile in LDS: 8 x 36 tokens x 64 B
+constexpr int kAdPerWave = 2 * kAdTile / 1024 / 4;            // LDS-DMA pieces per wave and head pair (9)
+static_assert(2 * kAdTile == 4 * kAdPerWave * 1024, "the K and V tiles must split into whole pieces over 4 waves");
+constexpr int kSpaBLds = 4 * kAdTile + 1024;                  // two K+V buffers + LayerNorm parameters
+// phase B re-uses the two K / V buffers: ring slots 0..3 in buffer A, slots 4,5 and the tile I/O scratch in buffer B
+static_assert(4 * kSpaBChunk * 1024 <= 2 * kAdTile, "ring slots 0..3 must fit buffer A");
+static_assert(2 * kSpaBChunk * 1024 + 4 * TileIO<4, bf16_t>::BYTES <= 2 * kAdTile, "ring slots 4,5 + scratch must fit buffer B");
+
+// Two 16-byte query fragments of one head pair, loaded by inline asm so that hipcc neither counts them nor drains the
+// LDS-DMA in flight when they are used (it waits vmcnt(0) for ordinary loads while a global_load_lds is outstanding).
+// They complete with the counted wait at the top of their head pair's iteration (vmcnt retires in issue order).
+LFT_DEV void q_load_async(const bf16_t* p0, const bf16_t* p1, raw16& a, raw16& b) {
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off" : "=&v"(a), "=&v"(b) : "v"(p0), "v"(p1) : "memory");
+}
+template <int N> LFT_DEV void wait_vm_q(raw16& a, raw16& b) {          // s_waitcnt vmcnt(N); names the asm-loaded registers so no use moves above it
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool SKIP>
+__global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK, const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                  const bf16_t* __restrict__ Vv, const bf16_t* __restrict__ ws, const float* __restrict__ ln,
+                                                  const bf16_t* __restrict__ skip, bf16_t* __restrict__ Y, int h, int w) {
+    typedef bf16_t T;
+    using Ring = WRingDeep<T, kSpaBChunk, 4, kSpaBSlots>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ldsK = smem;
-    char* ldsV = smem + kAmSlots * kAmRow;
+    char* const bufA = smem;                                          // each buffer: K tile, then V tile, of one head pair
+    char* const bufB = smem + 2 * kAdTile;
+    float* lds_ln = reinterpret_cast<float*>(smem + 4 * kAdTile);
     const int tiles_x = (w + kAttTX - 1) / kAttTX, tiles_y = (h + kAttTY - 1) / kAttTY;
     const int bid = xcd_tile(blockIdx.x, gridDim.x);                  // vertically adjacent tiles share 4 of their 8 halo rows
     const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, im = bid / (tiles_x * tiles_y);
@@ -325,12 +245,47 @@ __global__ __launch_bounds__(256, 2) void k_spa_attn_mfma(const bf16_t* __restri
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int y0 = ty * kAttTY, x0 = tx * kAttTX, bxl = 8 * wave;          // block origin: (y0, x0 + bxl)
     const long long img0 = (long long)im * h * w;
-    AmPlan plan;
-    am_plan(plan, img0, y0, x0, h, w);
+    LFT_STAMP(16);
     // this lane's query
     const int qy = y0 + (r >> 3), qx = x0 + bxl + (r & 7);
-    const bool qok = qy < h && qx < w;
     const long long qtok = img0 + min(qy, h - 1) * w + min(qx, w - 1);
+    const bf16_t* qptr = Q + qtok * 128 + 8 * hh;                       // + 32 hg + 16 hl
+    // K / V halo tiles (8 x 36 tokens x 2 heads = 64 B per token, unpadded) come in by LDS-DMA: no staging registers, no
+    // LDS store instructions.  36 one-KiB pieces per head pair: waves 0,1 fetch K, waves 2,3 fetch V, 9 pieces each.  Piece
+    // u covers 16 tokens; lane l moves 16-byte unit 64 u + l = (token slot, quarter).  Tokens outside the image are
+    // fetched from the clamped position: finite values that the -inf bias (K) / zero probability (V) keep out of the result.
+    int dofs[kAdPerWave];                                             // byte offsets of this lane's units from the image's first token, head pair 0
+#pragma unroll
+    for (int i = 0; i < kAdPerWave; ++i) {
+        const int u = ((wave & 1) * kAdPerWave + i) * 64 + lane, slot = u >> 2, piece = u & 3;
+        const int gy = min(max(y0 - 2 + slot / kAttHC, 0), h - 1), gx = min(max(x0 - 2 + slot % kAttHC, 0), w - 1);
+        dofs[i] = ((gy * w + gx) * 128 + piece * 8) * 2;
+    }
+    // buffer form of the LDS-DMA: wave-uniform descriptor (this image's K or V) + a 32-bit per-lane offset, so the nine
+    // source addresses cost nine registers, not nine 64-bit pointers
+    const auto dsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>((wave < 2 ? K : Vv) + img0 * 128), 0, h * w * 256, 0x00020000);
+    const int ddst = (wave < 2 ? 0 : kAdTile) + (wave & 1) * kAdPerWave * 1024;       // this wave's part of a buffer
+    auto stage = [&](int hg, char* buf) {
+#pragma unroll
+        for (int i = 0; i < kAdPerWave; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dsrc, (__attribute__((address_space(3))) void*)(buf + ddst + i * 1024), 16, dofs[i], hg * 64, 0, 0);
+    };
+    // Pipeline (VM operations retire in issue order):  D0 D1 Q0 | it0: wait(0) .. Q1 D2 | it1: wait(9) .. Q2 D3 |
+    // it2: wait(9) .. Q3 R0-3 | it3: wait(8) .. R4 | phase B.   Dn = the 9 DMA pieces of head pair n, Qn = its two query
+    // loads, Rc = ring chunk c (2 pieces per wave).  The wait at the top of iteration n leaves only the group issued last
+    // in flight, so Dn and Qn have landed; a buffer is re-filled right after the barrier that ends its head pair.  Q0 is
+    // issued last in the prologue: between an asm load and its wait the compiler must have no reason to touch the
+    // destination registers (it does not know they are pending).
+    const raw16 lnv = params_load(ln + 256, 256);                     // feed_forward.0.{weight,bias}: stored to LDS after the first wait below
+    stage(0, bufA);
+    stage(1, bufB);
+    Ring ring;
+    ring.setup(ws, smem, 176, 4, 2 * kAdTile - 4 * kSpaBChunk * 1024);
+    // this wave's block of tokens in memory (clamped origin: readable even when the block lies outside the image)
+    BlkRows rows;
+    rows.nrow = max(0, min(4, h - y0)); rows.ncol = max(0, min(8, w - (x0 + bxl)));
+    if (rows.ncol == 0) rows.nrow = 0;
+    const long long tok0 = img0 + (long long)min(y0, h - 1) * w + min(x0 + bxl, w - 1);
     // 0 / -inf bias of the three score tiles: key kk = 32 j + row -> (jy, jx) = (kk / 12, kk % 12) of the 12 x 8 neighbourhood
     f32x16 bias[3];
     {
@@ -344,51 +299,83 @@ __global__ __launch_bounds__(256, 2) void k_spa_attn_mfma(const bf16_t* __restri
                 bias[j][i] = (ky >= wy0 && ky < wy1 && kx >= wx0 && kx < wx1) ? 0.0f : -INFINITY;
             }
     }
-    // LDS byte offsets of this lane's operand rows: K fragment rows (key = 32 j + r), V^T transposing reads
     int kofs[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int kk = 32 * j + r;
-        kofs[j] = ((kk / 12) * kAttHC + bxl + kk % 12) * kAmRow + hh * 16;
+        kofs[j] = ((kk / 12) * kAttHC + bxl + kk % 12) * 64 + hh * 16;
     }
+    // V^T transposing reads: element group `wh` of k-step (j, s2) covers keys kk = c + t .. with c = 32 j + 16 s2 + 8 wh
+    // (compile time) and t = 4 hh + tq (lane); its slot is kk + 24 (kk / 12) + bxl, and (c + t) / 12 = c / 12 + (c % 12 == 8 && hh):
+    // two per-lane bases + compile-time offsets (folded into the instruction) instead of twelve address registers.
     const int li = lane & 15, tq = li >> 2, tp = li & 3, g2 = (lane >> 4) & 1;
-    int vofs[3][2][2];
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int wh = 0; wh < 2; ++wh) {
-                const int kk = 32 * j + 16 * s2 + 8 * wh + 4 * hh + tq;                 // acc-order key of element group `wh`, row tq of the 4-row block
-                vofs[j][s2][wh] = ((kk / 12) * kAttHC + bxl + kk % 12) * kAmRow + (16 * g2 + 4 * tp) * 2;
-            }
-
-#pragma unroll 1
+    const int vb0 = kAdTile + (4 * hh + tq + bxl) * 64 + (16 * g2 + 4 * tp) * 2;
+    const int vb1 = vb0 + 24 * 64 * hh;
+    LFT_STAMP(17);
+    raw16 qa, qb;
+    q_load_async(qptr, qptr + 16, qa, qb);
+    Frag<T> of[8];                                                    // attention output of all 8 heads: out_proj's B operand, acc order
+#pragma unroll                        // of[] needs compile-time indices (a runtime index would put it in scratch)
     for (int hg = 0; hg < 4; ++hg) {
-        Frag<bf16_t> qf[2];
-#pragma unroll
-        for (int hl = 0; hl < 2; ++hl)
-            qf[hl].v = *reinterpret_cast<const bf16x8*>(Q + qtok * 128 + (2 * hg + hl) * 16 + 8 * hh);
-        {
-            raw16 kv[AmPlan::ITER], vv[AmPlan::ITER];
-            am_load(plan, K, hg, kv);
-            am_load(plan, Vv, hg, vv);
-            if (hg) __syncthreads();                                       // previous head pair fully consumed
-            am_store(plan, ldsK, kv);
-            am_store(plan, ldsV, vv);
-        }
-        __syncthreads();
-        // one accumulator per head: the V^T operand holds BOTH heads' 32 channels on its 32 rows, so each product
-        // also fills the other head's 16 rows with garbage -- simply never read (cheaper than masking the operand)
-        f32x16 o[2];
+        char* const buf = (hg & 1) ? bufB : bufA;
+        if (hg == 0) { wait_vm_q<0>(qa, qb); params_store(lds_ln, 256, lnv); }
+        else if (hg < 3) wait_vm_q<kAdPerWave>(qa, qb);
+        else wait_vm_q<4 * Ring::PIECES_PER_WAVE>(qa, qb);
+        wg_barrier_keep_vm();                                              // everybody's pieces of this head pair have landed
+        LFT_STAMP(18 + 2 * hg);
+        Frag<T> qf[2];
+        qf[0].v = __builtin_bit_cast(bf16x8, qa);
+        qf[1].v = __builtin_bit_cast(bf16x8, qb);
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl) {
-            f32x16 S[3];
+#if LFT_SPAB_TWOPASS
+            // Two passes over the three score tiles, the second one RECOMPUTING them (3 more MFMAs on an idle matrix pipe):
+            // only one 32 x 32 score tile is live at a time instead of three -- 32 registers that decide between a clean
+            // allocation and spills inside this loop (a spill reload drains the LDS-DMA in flight).
+            f32x16 o;
             float m = -INFINITY;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                Frag<bf16_t> kf;
-                kf.v = __builtin_bit_cast(bf16x8, load_raw16(ldsK + kofs[j] + hl * 32));
+                Frag<T> kf;
+                kf.v = __builtin_bit_cast(bf16x8, load_raw16(buf + kofs[j] + hl * 32));
+                const f32x16 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, qf[hl].v, bias[j], 0, 0, 0);   // S^T[key, q] + mask bias
+#pragma unroll
+                for (int i = 0; i < 16; ++i) m = fmaxf(m, S[i]);
+            }
+            m = fmaxf(xhalf_max(m), -1.0e30f);                               // empty window: keep exp2(-inf - m) = 0, not NaN
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                Frag<T> kf;
+                kf.v = __builtin_bit_cast(bf16x8, load_raw16(buf + kofs[j] + hl * 32));
+                asm volatile("" : "+v"(kf.v));                             // opaque: otherwise the two passes are merged and all three tiles stay live
+                f32x16 P = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, qf[hl].v, bias[j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { P[i] = fast_exp2(P[i] - m); sum += P[i]; }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int c0 = 32 * j + 16 * s2, c1 = c0 + 8;
+                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(buf + (c0 % 12 == 8 ? vb1 : vb0) + (c0 + 24 * (c0 / 12)) * 64));
+                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(buf + (c1 % 12 == 8 ? vb1 : vb0) + (c1 + 24 * (c1 / 12)) * 64));
+                    Frag<T> vf;
+                    vf.v = __builtin_bit_cast(bf16x8, (short __attribute__((ext_vector_type(8)))){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
+                    mma(vf, acc_to_frag(P, s2, T()), o);                      // O^T[d, q] += V^T P^T (rows of BOTH heads; only this head's 16 are kept)
+                }
+                __builtin_amdgcn_sched_barrier(0);                         // one score tile at a time (the scheduler would overlap all three again)
+            }
+            sum = xhalf_sum(sum);
+            const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;                // empty window (h < w quirk): 0, as the pinned reference
+#else
+            f32x16 S[3], o;
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                Frag<T> kf;
+                kf.v = __builtin_bit_cast(bf16x8, load_raw16(buf + kofs[j] + hl * 32));
                 S[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, qf[hl].v, bias[j], 0, 0, 0);   // S^T[key, q] + mask bias
 #pragma unroll
                 for (int i = 0; i < 16; ++i) m = fmaxf(m, S[j][i]);
@@ -402,64 +389,48 @@ __global__ __launch_bounds__(256, 2) void k_spa_attn_mfma(const bf16_t* __restri
             sum = xhalf_sum(sum);
             const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;                // empty window (h < w quirk): 0, as the pinned reference
 #pragma unroll
-            for (int i = 0; i < 16; ++i) o[hl][i] = 0.0f;
+            for (int i = 0; i < 16; ++i) o[i] = 0.0f;
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
+                    const int c0 = 32 * j + 16 * s2, c1 = c0 + 8;
                     const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(ldsV + vofs[j][s2][0]));
+                        (__attribute__((address_space(3))) s16x4*)(buf + (c0 % 12 == 8 ? vb1 : vb0) + (c0 + 24 * (c0 / 12)) * 64));
                     const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(ldsV + vofs[j][s2][1]));
-                    Frag<bf16_t> vf;
+                        (__attribute__((address_space(3))) s16x4*)(buf + (c1 % 12 == 8 ? vb1 : vb0) + (c1 + 24 * (c1 / 12)) * 64));
+                    Frag<T> vf;
                     vf.v = __builtin_bit_cast(bf16x8, (short __attribute__((ext_vector_type(8)))){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
-                    mma(vf, acc_to_frag(S[j], s2, bf16_t()), o[hl]);          // O^T[d, q] += V^T P^T
+                    mma(vf, acc_to_frag(S[j], s2, T()), o);                   // O^T[d, q] += V^T P^T (rows of BOTH heads; only this head's 16 are kept)
                 }
+#endif
+            // rows 16 hl .. 16 hl + 15 (registers 8 hl .. 8 hl + 7) are this head's channels 32 hg + 16 hl + ..: k-step 2 hg + hl of out_proj
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[hl][8 * hl + i] *= inv;           // rows 16 hl .. 16 hl + 15 are this head's
+            for (int i = 0; i < 8; ++i) of[2 * hg + hl].v[i] = (bf16_t)(o[8 * hl + i] * inv);
+            // keep the heads apart: left alone, the scheduler interleaves two heads (two sets of score tiles live) and
+            // hoists the next head pair's work over this one's softmax -- 100+ spilled registers
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (qok) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x16& oo = o[g >> 1];                                // pieces 0,1 (rows 0-15): head 0; pieces 2,3: head 1
-                store4(O + qtok * 128 + hg * 32 + 8 * g + 4 * hh, f32x4{oo[4 * g], oo[4 * g + 1], oo[4 * g + 2], oo[4 * g + 3]});
-            }
-        }
+        LFT_STAMP(19 + 2 * hg);
+        wg_barrier_keep_vm();                                              // every wave is done reading this buffer
+        if (hg < 3) q_load_async(qptr + 32 * (hg + 1), qptr + 32 * (hg + 1) + 16, qa, qb);
+        if (hg < 2) stage(hg + 2, buf);
+        else if (hg == 2) { ring.issue(0); ring.issue(1); ring.issue(2); ring.issue(3); }      // buffer A now belongs to the weight ring
+        else ring.issue(4);                                                                    // ... and so does buffer B
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// SpaTrans part 2 (reference LFT.py:187-189, 171-174): per 32-token tile
-//   t  = tok + O Wo^T ;  t2 = t + W2 relu(W1 LN'(t)) ;  y = Wl t2  (Conv3d 1x1x1 128->64)  [+ global skip, LFT.py:76]
-// FFN hidden width 256 is processed in four 64-wide chunks so the hidden activations never leave registers.
-// Stream: Wo[4x8, natural k] {W1c[2x8] W2c[4x4]} x4  Wl[2x8]  (176 fragments).
-// ------------------------------------------------------------------------------------------
-template <typename T, bool SKIP, bool TOKLM = false, bool YLM = false>   // YLM: output tile in lane-major form (consumer: k_up)
-__global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa2(const T* __restrict__ TOK, const T* __restrict__ O, const T* __restrict__ ws,
-                                              const float* __restrict__ ln, const T* __restrict__ skip, T* __restrict__ Y,
-                                              long long ntok) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const int wave = threadIdx.x >> 6;
-    const long long t0 = ((long long)blockIdx.x * 4 + wave) * 32;                     // this wave's 32 consecutive tokens
-    const int nvalid = (int)max(0LL, min(32LL, ntok - t0));
-    const long long tb = min(t0, ntok - 1);
-    char* scr = smem + WRing<T, kSpaChunk>::LDS_BYTES + 1024 + wave * TileIO<4, T>::BYTES;   // wave-private tile I/O scratch
-    WRing<T, kSpaChunk> ring;
-    ring.init(ws, smem, 176);                 // first: the weight DMA is in flight while the activation tiles are fetched
+    char* scr = bufB + 2 * kSpaBChunk * 1024 + wave * TileIO<4, T>::BYTES;
     f32x16 t[4], n[4];
-    if constexpr (TOKLM) load_tile_lm<4, T>(TOK + tb * 128, lane, t);       // written by k_spa1 in the same 32-token tiling
-    else load_tile<4, T>(TOK + tb * 128, nvalid, lane, t, scr);
-    Frag<T> f[8];
-    load_tile_frags<8, T>(O + tb * 128, nvalid, lane, f, scr);
-    f32x16 sk[2];
-    if (SKIP) load_tile<2, T>(skip + tb * 64, nvalid, lane, sk, scr);
-    float* lds_ln = reinterpret_cast<float*>(smem + WRing<T, kSpaChunk>::LDS_BYTES);
-    params_store(lds_ln, 256, params_load(ln + 256, 256));            // feed_forward.0.{weight,bias}; the tile loads above were waited for anyway; published by the first ring barrier
-    linear_ring<4, 8, T>(ring, f, t);
+    {
+        BlkRows rt = rows; rt.img_row_bytes = w * 256; rt.tok_bytes = 256;
+        load_tile_map<4, T>(TOK + tok0 * 128, rt, lane, t, scr);
+    }
+    LFT_STAMP(26);
+    linear_ring<4, 8, T>(ring, of, t);                                // t = tok + O Wo^T
+    LFT_STAMP(27);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] = t[nt];
     layernorm_acc<4>(n, lds_ln, lds_ln + 128, hh);
+    Frag<T> f[8];
     acc_frags<4, T>(n, f);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -474,16 +445,21 @@ __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa2(const T* __restrict__
         acc_frags<2, T>(hid, hf);
         linear_ring<4, 4, T>(ring, hf, t);
     }
+    LFT_STAMP(28);
     acc_frags<4, T>(t, f);
     f32x16 y[2];
     zero_acc<2>(y);
     linear_ring<2, 8, T>(ring, f, y);
+    LFT_STAMP(29);
+    BlkRows ry = rows; ry.img_row_bytes = w * 128; ry.tok_bytes = 128;
     if (SKIP) {
+        f32x16 sk[2];
+        load_tile_map<2, T>(skip + tok0 * 64, ry, lane, sk, scr);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) y[nt] += sk[nt];
     }
-    if constexpr (YLM) store_tile_lm<2, T>(Y + tb * 64, lane, y);
-    else store_tile<2, T>(Y + tb * 64, nvalid, lane, y, scr);
+    store_tile_map<2, T>(Y + tok0 * 64, ry, lane, y, scr);
+    LFT_STAMP(30);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -494,18 +470,18 @@ __global__ __launch_bounds__(256, LFT_SPA_OCC) void k_spa2(const T* __restrict__
 // U is produced 32 rows at a time and immediately contracted into G.
 // Stream per chunk c: Wu[1x4] M[GT x 2].  G rows >= (s+2)^2 are padding.
 // ------------------------------------------------------------------------------------------
-template <typename T, int GT, bool XLM = false>   // XLM: input tile in lane-major form (producer: the last k_spa2)
-__global__ __launch_bounds__(256) void k_up(const T* __restrict__ X, const T* __restrict__ ws, float* __restrict__ G,
+template <typename T, int GT, bool XLM = false, int NW = kNwUp>   // XLM: input tile in lane-major form (producer: the last k_spa2)
+__global__ __launch_bounds__(64 * NW) void k_up(const T* __restrict__ X, const T* __restrict__ ws, float* __restrict__ G,
                                             long long ntok, int nchunk, int gp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-    const long long tok_raw = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + r;
+    const long long tok_raw = ((long long)blockIdx.x * NW + (threadIdx.x >> 6)) * 32 + r;
     const bool ok = tok_raw < ntok;
     const long long tok = ok ? tok_raw : ntok - 1;
     const long long t0 = tok_raw - r;
     const int nvalid = (int)max(0LL, min(32LL, ntok - t0));
-    char* scr = smem + WRing<T, kUpChunk>::LDS_BYTES + (threadIdx.x >> 6) * TileIO<2, T>::BYTES;
-    WRing<T, kUpChunk> ring;
+    char* scr = smem + WRing<T, kUpChunk, NW>::LDS_BYTES + (threadIdx.x >> 6) * TileIO<2, T>::BYTES;
+    WRing<T, kUpChunk, NW> ring;
     ring.init(ws, smem, nchunk * (4 + 2 * GT));         // first: the weight DMA is in flight while the tile is fetched
     f32x16 x[2];
     if constexpr (XLM) load_tile_lm<2, T>(X + t0 * 64, lane, x);
@@ -569,40 +545,18 @@ LFT_DEV float bicubic_at(const float* __restrict__ view, int stride, int h, int 
     }
     return acc;
 }
-template <int S>
-__global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ lr, const float* __restrict__ G, float* __restrict__ out,
-                                                  int B, int A, int h, int w, int with_body) {
-    // grid: x = 256-pixel column groups, y = HR mosaic row, z = batch.  Row quantities are block-uniform (scalar),
-    // S is a compile-time power of two, so the per-thread index math has a single division (view column).
-    const int HR_H = A * h * S, HR_W = A * w * S;
+// The per-view bicubic skip on its own (lft_bicubic_fwd: unit tests of reference LFT.py:255-266).
+__global__ __launch_bounds__(256) void k_bicubic(const float* __restrict__ lr, float* __restrict__ out, int B, int A, int h, int w, int s) {
+    // grid: x = 256-pixel column groups, y = HR mosaic row, z = batch
+    const int HR_H = A * h * s, HR_W = A * w * s;
     const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y, b = blockIdx.z;
     if (X >= HR_W) return;
-    const int a1 = Y / (h * S), a2 = X / (w * S);
+    const int a1 = Y / (h * s), a2 = X / (w * s);
     const float* view = lr + (size_t)b * (A * h) * (A * w) + (size_t)(a1 * h) * (A * w) + a2 * w;
-    float v = bicubic_at(view, A * w, h, w, Y - a1 * h * S, X - a2 * w * S, S);
-    if (with_body) {
-        constexpr int GP = (S + 2) * (S + 2);
-        const int hw = h * w, V = A * A;
-        const int qy = Y / S, qx = X / S, i = Y % S, j = X % S;
-        const float* Gb = G + (size_t)b * V * hw * GP;
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int I = i - S * dy, by = qy + dy;
-            if (I < -1 || I > S || by < 0 || by >= A * h) continue;
-            const int vy = by / h, py = by - vy * h;
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int J = j - S * dx, bx = qx + dx;
-                if (J < -1 || J > S || bx < 0 || bx >= A * w) continue;
-                const int vx = bx / w, px = bx - vx * w;
-                v += Gb[((size_t)(vy * A + vx) * hw + py * w + px) * GP + (I + 1) * (S + 2) + (J + 1)];
-            }
-        }
-    }
-    out[((size_t)b * HR_H + Y) * HR_W + X] = v;
+    out[((size_t)b * HR_H + Y) * HR_W + X] = bicubic_at(view, A * w, h, w, Y - a1 * h * s, X - a2 * w * s, s);
 }
 
-// Tiled form of the same gather (the one the forward uses): a workgroup owns an 8 x 8 block of LR mosaic pixels =
+// The gather is tiled: a workgroup owns an 8 x 8 block of LR mosaic pixels =
 // an 8S x 8S block of output pixels, and stages the (8+2)^2 footprints it can touch in LDS with coalesced 16-byte
 // loads (a footprint is (S+2)^2 contiguous floats) -- every footprint is fetched once per block instead of once per
 // output row that needs it, and the 4-float groups read by neighbouring lanes fall on distinct banks (row stride

@@ -417,7 +417,7 @@ int train_forward(const float* const* P, const float* lr, float* out, float* tap
     // final 3x3 conv over the mosaic + bicubic skip: overlap-add footprints G = M lrelu(U) (backward scratch gu holds them), then gather
     const int gt = (d.gp + 31) / 32;
     TRY(lin_fwd(c, VW_UPM, c.F(T.act), 0, nullptr, c.F(T.gu), N, 0, gt));
-    launch_assemble(lr, c.F(T.gu), out, d.B, d.A, d.h, d.w, d.s, 1, st, 32 * gt);
+    launch_assemble(lr, c.F(T.gu), out, d.B, d.A, d.h, d.w, d.s, st, 32 * gt);
     LFT_LAUNCH_OK("k_assemble_t");
     return 0;
 }

@@ -56,7 +56,31 @@ def gather_patches(local: torch.Tensor, n_total: int) -> torch.Tensor:
     return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
 
 
-def sum_gradients_(flat: torch.Tensor, group=None) -> float:
+def _force() -> bool:
+    # LFT_DP_FORCE_COLLECTIVES=1: issue the collectives even in a process group of one rank (a one-GPU box can then
+    # exercise the RCCL path end to end; numerically the identity).
+    return os.environ.get("LFT_DP_FORCE_COLLECTIVES", "0") == "1"
+
+
+def broadcast_(flat: torch.Tensor, src: int = 0, group=None, force: bool = False) -> torch.Tensor:
+    """In-place broadcast of a flat buffer from rank ``src`` (what DistributedDataParallel does with the parameters at
+    construction): data-parallel replicas must start from identical weights, and a freshly constructed network draws
+    them from each process's own RNG.  Identity without a process group.  gloo + device tensor: through the host."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat
+    if dist.get_world_size(group) == 1 and not (force or _force()):
+        return flat
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        host = flat.cpu()
+        dist.broadcast(host, src=src, group=group)
+        flat.copy_(host)
+    else:
+        dist.broadcast(flat, src=src, group=group)
+    return flat
+
+
+def sum_gradients_(flat: torch.Tensor, group=None, force: bool = False) -> float:
     """In-place SUM all-reduce of the flat gradient buffer over the data-parallel ranks; returns the factor
     (1 / world) that turns the sum of per-shard mean-loss gradients into the global-batch gradient (equal shards:
     L1Loss is a mean over the local shard, reference LFT.py:272).  One collective per step.
@@ -65,7 +89,7 @@ def sum_gradients_(flat: torch.Tensor, group=None) -> float:
     if not (dist.is_available() and dist.is_initialized()):
         return 1.0
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not (force or _force()):
         return 1.0
     if flat.is_cuda and dist.get_backend(group) == "gloo":
         host = flat.cpu()

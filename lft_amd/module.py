@@ -119,9 +119,11 @@ class get_model(nn.Module):
         B, _, H, W = lr.shape
         if H % A or W % A:
             raise ValueError(f"mosaic {H}x{W} is not divisible by angRes {A}")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # training (reference train.py:89-107): the fp32 forward-with-tape / backward kernels, whatever self.precision
-            # says; gradients reach the 78 parameters, none flows to the input (the reference's data has none either)
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training (reference train.py:89-107; nn.Module starts in training mode, as the reference's net does): the
+            # fp32 forward-with-tape / backward kernels, whatever self.precision says; gradients reach the 78 parameters,
+            # none flows to the input (the reference's data has none either).  After net.eval() (reference test.py:53)
+            # forward is the inference path and builds no autograd graph, with or without torch.no_grad().
             from .train import LFTFunction
             return LFTFunction.apply(lr.contiguous().float(), A, s, self.train_math, *self._params_in_order())
         h, w = H // A, W // A

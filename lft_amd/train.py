@@ -160,6 +160,10 @@ class TrainStep:
                 p.grad = self.flat_grads[off:off + k].view(p.shape)
                 off += k
         self.params = ps
+        # Replicas must start from the same weights (the reference has no DP; torch's DDP broadcasts rank 0's
+        # parameters at construction): a network built from scratch draws its weights from this process's own RNG.
+        from .dp import broadcast_
+        broadcast_(self.flat_params, src=0, group=self.group)
         self.t = 0
         self._tape = None
         self._scratch = torch.empty(1024 + 1, dtype=torch.float32, device=dev)

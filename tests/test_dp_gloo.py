@@ -94,3 +94,40 @@ def test_two_rank_gradient_sum_equals_full_batch_gradient():
         assert p.exitcode == 0
     assert ret.get(0) and ret.get(1)
     assert dp.sum_gradients_(torch.ones(4)) == 1.0          # no process group: identity
+
+
+def _init_worker(rank, world, port, ret):
+    """Networks built from scratch (no load_state_dict) differ between processes; TrainStep must make them equal."""
+    from types import SimpleNamespace
+    from lft_amd.train import TrainStep
+    from model import LFT
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(1234 + rank)                                   # what two fresh processes effectively have
+        net = LFT.get_model(SimpleNamespace(channels=64, angRes=2, scale_factor=2))
+        before = torch.cat([p.detach().reshape(-1) for p in net._params_in_order()]).clone()
+        ts = TrainStep(net, graph=False)                                 # host-side construction only: no GPU needed
+        got = [torch.empty_like(ts.flat_params) for _ in range(world)]
+        dist.all_gather(got, ts.flat_params)
+        first = [torch.empty_like(before) for _ in range(world)]
+        dist.all_gather(first, before)
+        same_after = all(torch.equal(got[0], g) for g in got)
+        differed_before = not torch.equal(first[0], first[1])
+        views_ok = torch.equal(torch.cat([p.detach().reshape(-1) for p in net._params_in_order()]), got[0])
+        ret[rank] = same_after and differed_before and views_ok and torch.equal(got[0], first[0])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainstep_broadcasts_rank0_weights():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_init_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(0) and ret.get(1)

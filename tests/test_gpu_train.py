@@ -226,6 +226,60 @@ def test_two_rank_dp_step_equals_single_rank(tmp_path):
     assert float(d.max()) <= 1.05 * 2 * 2e-4 and float(d.mean()) <= 2e-5
 
 
+def test_two_rank_dp_from_scratch_keeps_replicas_identical(tmp_path):
+    """No load_state_dict: each rank constructs its own randomly initialised network.  TrainStep broadcasts rank 0's
+    weights, so after two data-parallel Adam steps both replicas hold bit-identical parameters."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(__file__), "dp_train_worker.py")
+    out = str(tmp_path / "scratch.pt")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29613", worker, "2", out, "scratch"], check=True, env=env, timeout=300)
+    a, b = torch.load(out + ".rank0"), torch.load(out + ".rank1")
+    assert torch.equal(a["flat"], b["flat"])
+
+
+def test_rccl_backend_runs_the_collectives_on_device(tmp_path):
+    """init_process_group("nccl") (= RCCL on ROCm; world size 1 is what a one-GPU box allows) and the data-parallel
+    collectives on DEVICE tensors: the timing all-reduce of bench.py, the parameter broadcast, the flat-gradient sum and
+    a whole TrainStep.step.  A child process, so the process group does not leak into the other tests."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+from types import SimpleNamespace
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from lft_amd import dp, train as T
+from lft_amd.params import deterministic_state, synthetic_lr
+from model import LFT
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+assert dp.barrier_max_seconds(1.5, dev) == 1.5                       # all_reduce(MAX) on a device tensor through RCCL
+g = torch.arange(1000, dtype=torch.float32, device=dev)
+ref = g.clone()
+assert dp.sum_gradients_(g, force=True) == 1.0 and torch.equal(g, ref)   # ncclAllReduce(SUM), one rank: identity
+dp.broadcast_(g, force=True); assert torch.equal(g, ref)
+A, s, B, h, w = 3, 2, 2, 6, 6
+net = LFT.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=s))
+net.load_state_dict({k: torch.from_numpy(v) for k, v in deterministic_state(64, s, seed=1, flavor="stress").items()})
+ts = T.TrainStep(net.to(dev).train(), lr=2e-4)
+lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=0)).to(dev)
+hr = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).random((B, 1, A * h * s, A * w * s), dtype=np.float32)).to(dev)
+l0 = float(ts.step(lr, hr)); l1 = float(ts.step(lr, hr))
+assert np.isfinite(l0) and l1 < l0, (l0, l1)
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK")
+"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", LFT_DP_FORCE_COLLECTIVES="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_fit_trains_and_writes_reference_format_checkpoints(tmp_path):
     """lft_amd.trainer.fit (the reference's epoch loop, train.py:86-110) on a small synthetic set: the loss goes down, the
     per-epoch .pth files have the reference's name / keys and reload into a fresh model that reproduces the outputs."""

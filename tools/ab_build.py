@@ -1,22 +1,50 @@
 #!/usr/bin/env python3
-"""A/B harness (GPU box): build liblft_hip variants with extra -D flags, run the bench's per-kernel breakdown
-for each variant in a fresh subprocess, print one line per variant.  Variants that change results
+"""A/B harness: liblft_hip variants built with extra -D flags, timed by bench.py's per-kernel breakdown, each run
+in a fresh subprocess, several interleaved rounds; prints one line per variant and round.  Variants that change results
 (LFT_EXP_*) are for timing experiments only.
-usage: tools/ab_build.py name1:-DFLAG1,-DFLAG2 name2: ...      ("name:" = no extra flags)"""
+
+  tools/ab_build.py --build name1:-DFLAG1,-DFLAG2 name2: ...   build only (hipcc cross-compiles without a GPU) into ab_so/
+  tools/ab_build.py name1:-DFLAG1 name2: ...                   build what is missing, then time (GPU box)
+  AB_ROUNDS=3 AB_TEST=1 ...                                    rounds; AB_TEST=1 also runs the GPU parity tests per variant
+("name:" = no extra flags).  ab_so/ is git-ignored but travels with gpurun, so variants are built here, not on GPU time."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-outdir = os.path.join(ROOT, "gpurun_out", "ab"); os.makedirs(outdir, exist_ok=True)
-variants = [a.split(":", 1) for a in sys.argv[1:]] or [["base", ""]]
+outdir = os.path.join(ROOT, "ab_so"); os.makedirs(outdir, exist_ok=True)
+args = sys.argv[1:]
+build_only = bool(args) and args[0] == "--build"
+if build_only:
+    args = args[1:]
+variants = [a.split(":", 1) for a in args] or [["base", ""]]
+procs = []
 for name, flags in variants:
     so = os.path.join(outdir, f"liblft_{name}.so")
+    if os.path.exists(so) and not build_only:
+        continue
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + [f for f in flags.split(",") if f] + \
           [os.path.join(ROOT, "lft_amd/csrc/lft_api.hip"), "-o", so]
-    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    procs.append((name, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
+    if len(procs) >= 4:
+        for n, p in procs:
+            if p.wait() != 0: raise SystemExit(f"build of {n} failed")
+        procs = []
+for n, p in procs:
+    if p.wait() != 0: raise SystemExit(f"build of {n} failed")
+if build_only:
+    raise SystemExit(0)
+extra = os.environ.get("AB_BENCH_ARGS", "").split()
+if os.environ.get("AB_TEST"):
+    for name, flags in variants:
+        env = dict(os.environ, LFT_LIB_PATH=os.path.join(outdir, f"liblft_{name}.so"))
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_parity.py", "tests/test_gpu_module.py",
+                            "tests/test_gpu_determinism.py"], env=env, capture_output=True, text=True, cwd=ROOT)
+        print(f"[test] {name:14s} rc={r.returncode} {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]}", flush=True)
+        if r.returncode != 0:
+            print(r.stdout[-3000:], flush=True)
 rounds = int(os.environ.get("AB_ROUNDS", "2"))
 for rnd in range(rounds):
     for name, flags in variants:
         env = dict(os.environ, LFT_LIB_PATH=os.path.join(outdir, f"liblft_{name}.so"))
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "15", "--no-cpu-baseline"],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "15", "--no-cpu-baseline"] + extra,
                            env=env, capture_output=True, text=True)
         try:
             j = json.loads(r.stdout.strip().splitlines()[-1])

@@ -24,9 +24,9 @@ def run_and_read(which):
     for _ in range(3):
         _lib.check(L.lft_spa_block_fwd(pk.buf.data_ptr(), 1, xin.data_ptr(), None, act.data_ptr(), pk.work.data_ptr(), *pk.dims(), G.stream()), "spa")
     torch.cuda.synchronize()
-    buf = np.zeros(4096 * 16, dtype=np.uint64)
+    buf = np.zeros(4096 * 32, dtype=np.uint64)
     _lib.check(L.lft_debug_read_stamps(buf.ctypes.data, buf.size), "read")
-    return buf.reshape(4096, 16)[:nwg].astype(np.int64)
+    return buf.reshape(4096, 32)[:nwg].astype(np.int64)
 allst = run_and_read(0)
 def report(title, st, names):
     d = np.diff(st, axis=1)
@@ -43,3 +43,19 @@ first, second = st[:512], st[512:800]
 for nm, g in (("first-round WGs (block < 512)", first), ("second-round WGs", second)):
     print(f"{nm}: issue loads + DMA {np.mean(g[:,12]-g[:,0]):.0f}, wait vmcnt(0) {np.mean(g[:,13]-g[:,12]):.0f}, barrier {np.mean(g[:,1]-g[:,13]):.0f}, "
           f"conv {np.mean(g[:,2]-g[:,1]):.0f}, rest {np.mean(g[:,11]-g[:,2]):.0f}, total {np.mean(g[:,11]-g[:,0]):.0f}")
+
+report("k_spa_b", allst[:, 16:31], ["ring init, params, touch, DMA plan, bias, offsets", "head pair 0: K/V DMA + wait + barrier", "head pair 0: 2 heads",
+                                    "head pair 1: DMA + wait", "head pair 1: 2 heads", "head pair 2: DMA + wait", "head pair 2: 2 heads",
+                                    "head pair 3: DMA + wait", "head pair 3: 2 heads", "barrier + TOK tile load", "out_proj (32 MFMA, 4 chunks)",
+                                    "LN + FFN (128 MFMA, 16 chunks)", "1x1x1 conv (16 MFMA)", "store tile"])
+
+# k_ang: its own launch (stamps 0..11 of the first 512 workgroups; two pixel tiles per wave at this size)
+for _ in range(3):
+    _lib.check(L.lft_ang_block_fwd(pk.buf.data_ptr(), 1, xin.data_ptr(), act.data_ptr(), *pk.dims(), G.stream()), "ang")
+torch.cuda.synchronize()
+buf = np.zeros(4096 * 32, dtype=np.uint64)
+_lib.check(L.lft_debug_read_stamps(buf.ctypes.data, buf.size), "read")
+ang = buf.reshape(4096, 32)[:512].astype(np.int64)
+report("k_ang", ang[:, 0:12], ["weights DMA + wait + barrier", "tile 1: load", "tile 1: LN, Q/K/V (24 MFMA)", "tile 1: 8 heads attention (24 MFMA)",
+                               "tile 1: out_proj + FFN (40 MFMA)", "tile 1: store", "tile 2: load", "tile 2: LN, Q/K/V", "tile 2: attention",
+                               "tile 2: out_proj + FFN", "tile 2: store"])
