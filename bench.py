@@ -8,9 +8,15 @@ data-parallel shards (weak scaling, no data-path collective); one process per GP
 torch.distributed.run, barrier + synchronize on both sides of the timed region, max over ranks.
 
 Prints ONE JSON line on rank 0 with the extra objects
-  roofline     : for the dominant kernel (largest share of GPU time; HIP events on the launch stream, inside this run)
-                 its algorithmic FLOPs and HBM bytes per launch decide the bound -- dense bf16 MFMA peak 2.5 PFLOP/s
-                 (fp32 path 157.3 TFLOP/s) or HBM 8 TB/s -- and `achieved`/`frac` are quoted against that peak
+  roofline     : for the dominant kernel (largest share of GPU time).  Its algorithmic FLOPs and HBM bytes per launch
+                 decide the bound -- dense bf16 MFMA peak 2.5 PFLOP/s (fp32 path 157.3 TFLOP/s) or HBM 8 TB/s -- and
+                 `achieved`/`frac` are quoted against that peak.  `launch_ms` = mean of 50 launches of that kernel back to
+                 back between two HIP events on the launch stream (lft_kernel_time: no event between launches, so it is
+                 comparable with the rocprofv3 kernel trace under profiles/).  `traffic` = HBM-side bytes per launch from the
+                 committed PMC passes, only when they were taken on the very sources that are being timed (`source_hash`).
+  parity_path  : the exact-fp32 MFMA path (the one that meets BASELINE.json's 1e-3 relative tolerance), same workload, same
+                 run: patches/s, and both paths' measured error against the CPU oracle on one patch.
+  train        : BASELINE configs[2] on this GPU (A5, 2x, batch 8, Adam; one process = no all-reduce partner): ms/step, patches/s.
   cpu_baseline : the CPU oracle (a port of the reference's operator sequence, oracle/lft_oracle.py) timed on
                  this node's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -101,14 +107,15 @@ def kernel_breakdown(net, lr, reps: int):
     return {k: (t / c, c // reps) for k, (t, c) in acc.items()}     # name -> (mean ms per launch, launches per forward)
 
 
-def cpu_baseline(seconds: float):
+def cpu_baseline(seconds: float, lr=None):
     from lft_amd.params import deterministic_state, synthetic_lr
     from oracle import lft_oracle as O            # the checker, timed as the CPU baseline
     # threads = this process's CPU share (the GPU box gives 16 CPUs per GPU; os.cpu_count() reports the whole host)
     cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("LFT_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     sd = O.state_from_numpy(deterministic_state(64, S, seed=1))
-    lr = torch.from_numpy(synthetic_lr(1, A, H, W, seed=0))
+    if lr is None:
+        lr = torch.from_numpy(synthetic_lr(1, A, H, W, seed=0))
     O.forward(sd, lr, A, S)                        # warm
     n, t0 = 0, time.perf_counter()
     while True:
@@ -117,23 +124,115 @@ def cpu_baseline(seconds: float):
         dt = time.perf_counter() - t0
         if dt >= seconds or n >= 64:
             break
+    ref = O.forward(sd, lr, A, S)                  # the checker's output for patch 0 of rank 0's batch
     return {"value": n / dt, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} single-patch forwards (A5, 4x, 32x32 LR, fp32, torch {torch.__version__} CPU ops) in {dt:.1f} s"}
+            "sample": f"{n} single-patch forwards (A{A}, {S}x, {H}x{W} LR, fp32, torch {torch.__version__} CPU ops) in {dt:.1f} s"}, ref
 
 
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_v7_hbm_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources: ties a PMC traffic file to the build it was measured on."""
+    import hashlib
+    from lft_amd import _lib
+    hsh = hashlib.sha256()
+    for name in sorted(_lib.SOURCES):
+        hsh.update(open(os.path.join(_lib.CSRC, name), "rb").read())
+    return hsh.hexdigest()[:16]
 
 
 def traffic_from_profile(kernel: str, args) -> dict:
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
     runs, gfx950 correction; tools/collect_traffic.py).  PMC counters cannot be read from inside this process, so
-    the value is only reported for the exact workload the profile was taken on; otherwise null."""
+    the value is only reported for the exact workload AND the exact sources the profile was taken on; otherwise null."""
+    cur = source_hash()
     default = (A, S, H, W, args.batch, args.precision) == (5, 4, 32, 32, 4, "bf16")
     if default and os.path.exists(TRAFFIC_PROFILE):
-        k = json.load(open(TRAFFIC_PROFILE))["kernels"].get(kernel)
-        if k:
-            return {"traffic": k["total"], "traffic_source": "profiles/r01_v7_hbm_traffic.json"}
-    return {"traffic": None}
+        prof = json.load(open(TRAFFIC_PROFILE))
+        k = prof["kernels"].get(kernel)
+        if k and prof.get("source_hash") == cur:
+            return {"traffic": k["total"], "traffic_source": "profiles/r02_hbm_traffic.json", "source_hash": cur}
+        return {"traffic": None, "traffic_note": "profiles/r02_hbm_traffic.json was taken on other sources (hash %s)" % prof.get("source_hash"),
+                "source_hash": cur}
+    return {"traffic": None, "source_hash": cur}
+
+
+def kernel_time_ms(net, lr, kernel: str, reps: int = 50):
+    """Mean ms of one kernel, `reps` launches back to back between two HIP events (lft_kernel_time); None if unsupported."""
+    from lft_amd import _lib
+    from lft_amd.module import _PREC
+    B = lr.shape[0]
+    prec = _PREC[net.precision]
+    stream = torch.cuda.current_stream().cuda_stream
+    packed = net._ensure_packed(lr.device, H, W, prec, stream)
+    work = net._ensure_work(lr.device, B, H, W, prec, slot="profile")      # holds the activations of kernel_breakdown's forwards
+    ms = ctypes.c_float(0.0)
+    rc = _lib.lib().lft_kernel_time(kernel.encode(), packed.data_ptr(), work.data_ptr(), B, A, H, W, S, prec, reps, stream, ctypes.byref(ms))
+    return float(ms.value) if rc == 0 else None
+
+
+def timed_steps(step, lr, n, warm):
+    with torch.no_grad():
+        for _ in range(warm):
+            step(lr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(lr)
+        torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def parity_path(args, dev, lr, bf16_net):
+    """The exact-fp32 path on the same workload (hipGraph, same steps in flight), and both paths' error on patch 0."""
+    from lft_amd.module import PipelinedForward
+    from lft_amd.params import deterministic_state
+    from model import LFT
+    net = LFT.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=S), precision="fp32", streams=1)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in deterministic_state(64, S, seed=1).items()})
+    net = net.to(dev).eval()
+    pipe = PipelinedForward(net, lr, depth=max(1, args.inflight))
+    n = max(10, args.steps // 5)
+    dt = timed_steps(lambda x: pipe(), lr, n, 5)
+    with torch.no_grad():
+        out32 = net(lr[:1]).float().cpu()
+        out16 = bf16_net(lr[:1]).float().cpu() if bf16_net is not None else None
+    res = {"precision": "fp32 (v_mfma_f32_32x32x2_f32, fp32 storage)", "value": args.batch * n / dt, "unit": "patches/s", "steps": n,
+           "ms_per_step": dt / n * 1e3, "tolerance": "1e-3 * max|ref| (BASELINE.json north_star)"}
+    return res, out32, out16
+
+
+def train_object(dev, math: str):
+    """BASELINE configs[2] shape on this GPU: A5, 2x, 32x32 LR, batch 8, fp32 tape, Adam (reference train.py:77-83)."""
+    import numpy as np
+    from lft_amd import train as T
+    from lft_amd.params import deterministic_state, synthetic_lr
+    from model import LFT
+    A3, S3, B3 = 5, 2, 8
+    net = LFT.get_model(SimpleNamespace(channels=64, angRes=A3, scale_factor=S3))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in deterministic_state(64, S3, seed=1).items()})
+    net = net.to(dev).train()
+    lr = torch.from_numpy(synthetic_lr(B3, A3, 32, 32, seed=0)).to(dev)
+    hr = torch.from_numpy(np.random.Generator(np.random.PCG64([2, 0])).random((B3, 1, A3 * 32 * S3, A3 * 32 * S3), dtype=np.float32)).to(dev)
+    ts = T.TrainStep(net, lr=2e-4, math=math)
+    for _ in range(3):
+        ts.step(lr, hr)
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss = ts.step(lr, hr)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tflops = 3 * 58.85e9 * B3 * n / dt / 1e12                         # forward + 2x for backward, SURVEY.md 8d
+    out = {"workload": "LFT 5x5 angRes 2xSR training step, batch=8, 32x32 LR, Adam (BASELINE configs[2] on 1 GPU: no all-reduce partner)",
+           "math": math, "ms_per_step": dt / n * 1e3, "patches_per_s": B3 * n / dt, "steps": n,
+           "algorithmic_tflops": tflops, "fp32_peak_tflops": PEAK_TFLOPS["fp32"], "frac_of_fp32_peak": tflops / PEAK_TFLOPS["fp32"],
+           "tape_bytes": T.tape_bytes(B3, A3, 32, 32, S3), "loss": float(loss)}
+    del ts, net
+    torch.cuda.empty_cache()
+    return out
 
 
 def note(msg: str) -> None:
@@ -155,6 +254,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="steps in flight: captured forwards replayed round-robin on this many streams (1 = strictly one after the other)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the parity_path and train objects (A/B timing runs)")
     args = ap.parse_args()
     global A, S, H, W
     A, S, H, W = args.ang, args.scale, args.lr, args.lr
@@ -231,7 +331,12 @@ def main():
         total_ms = sum(ms * cnt for ms, cnt in kb.values())
         note("kernel ms/launch: " + ", ".join(f"{k}={ms:.3f}x{c}" for k, (ms, c) in kb.items()))
         dom = max(kb, key=lambda k: kb[k][0] * kb[k][1])
-        dom_ms, dom_cnt = kb[dom]
+        dom_ev_ms, dom_cnt = kb[dom]
+        with torch.no_grad():
+            dom_ms = kernel_time_ms(net, lr, dom)                       # back-to-back launches, no events in between
+        timing = "50 back-to-back launches between two HIP events (lft_kernel_time)"
+        if dom_ms is None:
+            dom_ms, timing = dom_ev_ms, "HIP event after every kernel (lft_forward_profiled)"
         peak = PEAK_TFLOPS[args.precision]
         bpt = bytes_per_token(S, 2 if args.precision == "bf16" else 4)
 
@@ -258,16 +363,32 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world} (independent shards)",
                        "streams_per_gpu": args.streams, "hip_graph": not args.no_graph, "steps_in_flight": (args.inflight if not args.no_graph else 1),
                        "algorithmic_gflop_per_patch": flops_patch / 1e9},
-            "roofline": dict(roof(dom, dom_ms), kernel=dom, **traffic_from_profile(dom, args), launch_ms=dom_ms, launches_per_forward=dom_cnt,
-                             gpu_ms_per_forward=total_ms,
+            "roofline": dict(roof(dom, dom_ms), kernel=dom, **traffic_from_profile(dom, args), launch_ms=dom_ms, launch_ms_method=timing,
+                             launch_ms_with_events=dom_ev_ms, launches_per_forward=dom_cnt, gpu_ms_per_forward=total_ms,
                              algorithmic_per_launch={"gflop": fpt[dom] * ntok / 1e9, "gbyte": bpt[dom] * ntok / 1e9},
+                             # a fully fused SpaTrans / AngTrans block would read x and write x once
+                             compulsory_gbyte_fused_block=2 * 64 * (2 if args.precision == "bf16" else 4) * ntok / 1e9,
                              kernels={k: dict(ms=round(ms, 4), n=c, **{kk: (round(vv, 3) if isinstance(vv, float) else vv)
                                                                          for kk, vv in roof(k, ms).items() if kk in ("bound", "achieved", "frac")})
                                       for k, (ms, c) in kb.items()}),
         }
+        tr = result["roofline"].get("traffic")
+        if tr:
+            result["roofline"]["wasted_traffic_ratio_vs_kernel_contract"] = tr / (bpt[dom] * ntok)
+        out32 = out16 = None
+        if world == 1 and not args.no_extras and args.precision == "bf16":
+            note("timing the exact-fp32 parity path ...")
+            result["parity_path"], out32, out16 = parity_path(args, dev, lr, net)
+            note("timing the training step (BASELINE configs[2] shape) ...")
+            result["train"] = train_object(dev, "fp32")
+            result["train"]["bf16x3"] = {k: v for k, v in train_object(dev, "bf16x3").items() if k in ("ms_per_step", "patches_per_s", "algorithmic_tflops")}
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle on host cores ...")
-            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            result["cpu_baseline"], ref = cpu_baseline(args.cpu_seconds, lr[:1].cpu())
+            if out32 is not None:                                       # the oracle as the checker of both paths (patch 0)
+                den = float(ref.abs().max())
+                result["parity_path"]["rel_max_err_vs_oracle"] = float((out32 - ref).abs().max()) / den
+                result["parity_path"]["headline_path_rel_max_err_vs_oracle"] = float((out16 - ref).abs().max()) / den
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

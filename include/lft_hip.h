@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LFT_ABI_VERSION 1
+#define LFT_ABI_VERSION 2
 #define LFT_PREC_F32 0
 #define LFT_PREC_BF16 1
 #define LFT_NUM_PARAMS 78
@@ -126,10 +126,11 @@ int lft_train_backward(const float* const* params, int nparams, const float* lr,
 /* get_loss (reference LFT.py:269-277, torch.nn.L1Loss): *loss = mean |sr - hr|; if dsr != NULL also
  * dsr = gscale * sign(sr - hr) (gscale = 1/n for d loss / d sr).  scratch1024: 1024 floats of device scratch. */
 int lft_l1_loss(const float* sr, const float* hr, long long n, float* dsr, float gscale, float* loss, float* scratch1024, void* stream);
-/* torch.optim.Adam step (train.py:77-83: betas (0.9, 0.999), eps 1e-8, weight_decay 0) on one flat fp32 buffer;
- * step counts from 1; the gradient is multiplied by gscale first (1/world_size after a sum all-reduce). */
+/* torch.optim.Adam step (train.py:77-83: betas (0.9, 0.999), eps 1e-8, weight_decay = --decay_rate, default 0) on one
+ * flat fp32 buffer; step counts from 1; the gradient is multiplied by gscale first (1/world_size after a sum all-reduce),
+ * then weight_decay * p is added (torch's L2 form); bias corrections are computed in double, as torch does. */
 int lft_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
-                  int step, float gscale, void* stream);
+                  int step, float gscale, float weight_decay, void* stream);
 
 /* ---- per-view quality metrics (reference utils/utils.py:56-88 cal_metrics, which calls scikit-image) ----
  * label, out: fp32 mosaics [B,1,A*h,A*w]; psnr, ssim: fp32 [B*A*A] in (b, u, v) order.  PSNR = 10 log10(R^2 / MSE) with

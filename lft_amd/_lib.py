@@ -73,7 +73,7 @@ _SIGS = {
     "lft_train_forward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lft_train_backward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lft_l1_loss": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
-    "lft_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
+    "lft_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_void_p]),
     "lft_view_metrics_scratch_bytes": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "lft_view_metrics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lft_debug_conv64": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

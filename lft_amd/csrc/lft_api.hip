@@ -137,12 +137,16 @@ template <typename K> int allow_lds(K kernel, size_t bytes, const char* name) {
     if (bytes <= 64 * 1024) return 0;
     // The attribute is sticky per kernel: set it once per (kernel, size) so that steady-state forwards -- and a
     // stream capture of them -- consist of kernel launches only.
-    static thread_local std::vector<std::pair<const void*, size_t>> done;
+    // The attribute belongs to the (device, kernel) pair: a thread that drives two GPUs must set it on each.
+    struct Done { int dev; const void* fn; size_t bytes; };
+    static thread_local std::vector<Done> done;
     const void* fn = reinterpret_cast<const void*>(kernel);
+    int dev = 0;
+    LFT_HIP_OK(hipGetDevice(&dev));
     for (const auto& d : done)
-        if (d.first == fn && d.second >= bytes) return 0;
+        if (d.dev == dev && d.fn == fn && d.bytes >= bytes) return 0;
     LFT_HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    done.emplace_back(fn, bytes);
+    done.push_back(Done{dev, fn, bytes});
     return 0;
 }
 
@@ -297,7 +301,7 @@ int init_features(const void* packed, const PackedLayout& L, const float* lr, T*
     int rc;
     if ((rc = allow_lds(k_conv64<T, false>, lds, "k_conv64"))) return rc;
     if ((rc = allow_lds(k_conv64<T, true>, lds, "k_conv64"))) return rc;
-    k_conv0<T><<<dim3((unsigned)((d.hw + 31) / 32), (unsigned)nimg), 256, 0, st>>>(lr, at<float>(packed, L.conv0_w), x0, d.B, d.A, d.h, d.w);
+    k_conv0<T><<<std::min<unsigned>(blocks_for(d.ntok, 32), 2048u), 256, 0, st>>>(lr, at<float>(packed, L.conv0_w), x0, d.B, d.A, d.h, d.w);
     LFT_LAUNCH_OK("k_conv0");
     k_conv64<T, false><<<nwg, 64 * kNwConv, lds, st>>>(x0, ta, nullptr, at<T>(packed, L.s_conv[0]), nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_conv64");
@@ -796,10 +800,10 @@ int lft_l1_loss(const float* sr, const float* hr, long long n, float* dsr, float
     return 0;
 }
 int lft_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
-                  int step, float gscale, void* stream) {
-    if (!p || !g || !m || !v || n < 1 || step < 1) return fail(LFT_ERR_ARG, "bad argument");
-    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-    k_adam<<<blocks_for(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2, gscale);
+                  int step, float gscale, float weight_decay, void* stream) {
+    if (!p || !g || !m || !v || n < 1 || step < 1 || weight_decay < 0.0f) return fail(LFT_ERR_ARG, "bad argument");
+    const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step)), bc2 = (float)(1.0 - std::pow((double)beta2, (double)step));   // in double, as torch.optim.Adam
+    k_adam<<<blocks_for(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2, gscale, weight_decay);
     LFT_LAUNCH_OK("k_adam");
     return 0;
 }

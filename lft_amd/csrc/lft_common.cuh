@@ -160,6 +160,18 @@ LFT_DEV void glds_piece(const char* __restrict__ gsrc, char* lds_dst, int lane) 
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// The same LDS-DMA issued from inline asm, for pipelines whose in-flight pieces must NOT be known to hipcc: after the
+// builtin form the compiler guards every later LDS read it cannot disambiguate with a vmcnt wait that drains the
+// prefetch (k_spa_b: an s_waitcnt vmcnt(4) in front of the first V read of a head pair, i.e. "next tile landed").  The
+// caller orders data by its own counted s_waitcnt + barrier.  M0 (LDS base of the DMA) is compiler-reserved: saved,
+// set and restored inside the one statement.  lds_dst must be wave-uniform.
+LFT_DEV void glds16_asm(const char* gsrc_lane, char* lds_dst) {
+    unsigned keep;
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc_lane), "s"(dst) : "memory");
+}
+
 // s_waitcnt vmcnt(n) for a value that is a compile-time constant after inlining (the switch folds away).
 #define LFT_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
 LFT_DEV void wait_vmcnt(int n) {

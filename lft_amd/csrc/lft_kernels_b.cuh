@@ -32,7 +32,7 @@ constexpr int kSpaChunk = LFT_SPA_CHUNK;   // fragments per ring chunk: one conv
 #define LFT_NW_SPA2 4
 #endif
 #ifndef LFT_NW_UP
-#define LFT_NW_UP 4
+#define LFT_NW_UP 8      // k_up is light on registers: eight waves share one weight stream (48 -> 42 us at B = 4)
 #endif
 constexpr int kNwSpa1 = LFT_NW_SPA1, kNwSpa2 = LFT_NW_SPA2, kNwUp = LFT_NW_UP;
 template <typename T, bool PE_ONLY, int CH = kSpaChunk, bool TOKLM = false, int NW = kNwSpa1>   // TOKLM: the token tile goes to k_spa2 in lane-major tile format
@@ -261,14 +261,13 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
         const int gy = min(max(y0 - 2 + slot / kAttHC, 0), h - 1), gx = min(max(x0 - 2 + slot % kAttHC, 0), w - 1);
         dofs[i] = ((gy * w + gx) * 128 + piece * 8) * 2;
     }
-    // buffer form of the LDS-DMA: wave-uniform descriptor (this image's K or V) + a 32-bit per-lane offset, so the nine
-    // source addresses cost nine registers, not nine 64-bit pointers
-    const auto dsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>((wave < 2 ? K : Vv) + img0 * 128), 0, h * w * 256, 0x00020000);
+    // Issued from inline asm (glds16_asm): the compiler must not know about the pieces in flight, or it drains them in
+    // front of the next LDS read.
+    const char* const dsrc = reinterpret_cast<const char*>((wave < 2 ? K : Vv) + img0 * 128);
     const int ddst = (wave < 2 ? 0 : kAdTile) + (wave & 1) * kAdPerWave * 1024;       // this wave's part of a buffer
     auto stage = [&](int hg, char* buf) {
 #pragma unroll
-        for (int i = 0; i < kAdPerWave; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(dsrc, (__attribute__((address_space(3))) void*)(buf + ddst + i * 1024), 16, dofs[i], hg * 64, 0, 0);
+        for (int i = 0; i < kAdPerWave; ++i) glds16_asm(dsrc + dofs[i] + hg * 64, buf + ddst + i * 1024);
     };
     // Pipeline (VM operations retire in issue order):  D0 D1 Q0 | it0: wait(0) .. Q1 D2 | it1: wait(9) .. Q2 D3 |
     // it2: wait(9) .. Q3 R0-3 | it3: wait(8) .. R4 | phase B.   Dn = the 9 DMA pieces of head pair n, Qn = its two query

@@ -834,10 +834,10 @@ __global__ void k_l1_final(const float* __restrict__ part, int nb, float inv_n, 
 // Adam (torch.optim.Adam defaults used by the reference, train.py:77-83: betas, eps, weight_decay 0), one flat
 // fp32 buffer of all parameters: p -= lr_t * m_hat / (sqrt(v_hat) + eps).  bc1 = 1 - b1^t, bc2 = 1 - b2^t.
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                       long long n, float lr, float b1, float b2, float eps, float bc1, float bc2, float gscale) {
+                       long long n, float lr, float b1, float b2, float eps, float bc1, float bc2, float gscale, float wd) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float gi = g[i] * gscale;
+    const float gi = g[i] * gscale + wd * p[i];                        // torch.optim.Adam weight_decay: L2 term added to the gradient
     const float mi = b1 * m[i] + (1.0f - b1) * gi;
     const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;

@@ -228,15 +228,20 @@ int lin_bwd(const TrainCtx& c, int view, const float* dY, const float* R, float*
 // Events ordering the side stream after the producers on the main stream (host objects, created once per thread and reused;
 // a re-record only affects waits enqueued after it).
 hipEvent_t next_event() {
-    static thread_local std::vector<hipEvent_t> pool;
-    static thread_local size_t cursor = 0;
-    if (cursor >= pool.size()) {
+    // one pool per (thread, device): an event belongs to the device that was current when it was created
+    struct Pool { std::vector<hipEvent_t> ev; size_t cursor = 0; };
+    static thread_local std::vector<Pool> pools;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+    if ((size_t)dev >= pools.size()) pools.resize((size_t)dev + 1);
+    Pool& p = pools[(size_t)dev];
+    if (p.cursor >= p.ev.size()) {
         hipEvent_t e = nullptr;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        pool.push_back(e);
+        p.ev.push_back(e);
     }
-    hipEvent_t e = pool[cursor];
-    cursor = (cursor + 1) % 256;                       // far more than one backward pass records
+    hipEvent_t e = p.ev[p.cursor];
+    p.cursor = (p.cursor + 1) % 256;                   // far more than one backward pass records
     return e;
 }
 // weight gradient of either: dW (+)= dY^T X  (taps = 1 or 9)
@@ -376,7 +381,7 @@ int train_forward(const float* const* P, const float* lr, float* out, float* tap
     k_pe_plain<<<blocks_for(std::max(d.V, d.hw) * 64, 256), 256, 0, st>>>(c.F(T.pe_ang), c.F(T.pe_spa), d.V, d.h, d.w);
     LFT_LAUNCH_OK("k_pe_plain");
     // conv_init0, conv_init + residual (LFT.py:65-66)
-    k_conv0<float><<<dim3((unsigned)((d.hw + 31) / 32), (unsigned)nimg), 256, 0, st>>>(lr, P[P_CONV0], c.F(T.x0), d.B, d.A, d.h, d.w);
+    k_conv0<float><<<std::min<unsigned>(blocks_for(d.ntok, 32), 2048u), 256, 0, st>>>(lr, P[P_CONV0], c.F(T.x0), d.B, d.A, d.h, d.w);
     LFT_LAUNCH_OK("k_conv0");
     TRY(lin_fwd(c, VW_CONV_F + 0, c.F(T.x0), 2, nullptr, c.F(T.c1), N));
     TRY(lin_fwd(c, VW_CONV_F + 1, c.F(T.c1), 2, nullptr, c.F(T.c2), N));

@@ -176,10 +176,17 @@ class GraphedForward:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.static_out = net(self.static_in, _slot_base=slot_base)
+            # The graph has the packed-weight buffer's address baked in: keep the buffer alive, and refuse to replay once
+            # the module has dropped or replaced it (optimizer step, load_state_dict, checkpoint load) -- a replay would
+            # read freed memory, not merely stale weights.
+            self._packed = net._packed
 
     def __call__(self, lr: torch.Tensor) -> torch.Tensor:
         if lr.shape != self.static_in.shape:
             raise ValueError(f"graph was captured for {tuple(self.static_in.shape)}, got {tuple(lr.shape)}")
+        if self.net._packed is not self._packed:
+            raise RuntimeError("the model's weights were re-packed or dropped since this graph was captured "
+                               "(optimizer step / load_state_dict): create a new GraphedForward")
         if lr.data_ptr() != self.static_in.data_ptr():
             self.static_in.copy_(lr)
         self.graph.replay()
@@ -205,6 +212,8 @@ class PipelinedForward:
         k = self.i % self.depth
         self.i += 1
         g, st = self.graphs[k], self.streams[k]
+        if g.net._packed is not g._packed:
+            raise RuntimeError("the model's weights were re-packed or dropped since this pipeline was captured: create a new PipelinedForward")
         st.wait_stream(torch.cuda.current_stream(g.static_in.device))       # the caller's input is ready
         with torch.cuda.stream(st):
             if lr is not None and lr.data_ptr() != g.static_in.data_ptr():

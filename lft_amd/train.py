@@ -132,8 +132,9 @@ class TrainStep:
     """
 
     def __init__(self, net, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, math: Optional[str] = None,
-                 graph: bool = True):
+                 graph: bool = True, weight_decay: float = 0.0):
         self.net, self.lr, self.betas, self.eps = net, float(lr), betas, float(eps)
+        self.weight_decay = float(weight_decay)                        # reference train.py:82 weight_decay=args.decay_rate (option.py default 0)
         self.math = math or getattr(net, "train_math", "fp32")
         # forward + loss + backward are ~450 kernel launches; for a fixed batch shape they are captured once into a HIP
         # graph and replayed (the kernels read the weights through the same flat buffer every step, and re-pack them
@@ -223,7 +224,7 @@ class TrainStep:
             self.t += 1
             _lib.check(L.lft_adam_step(self.flat_params.data_ptr(), self.flat_grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                        self.flat_params.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.t,
-                                       gscale, stream), "lft_adam_step")
+                                       gscale, self.weight_decay, stream), "lft_adam_step")
         self.net._packed = None            # the inference path must re-pack the new weights
         return loss.clone()
 

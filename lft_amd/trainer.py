@@ -139,7 +139,7 @@ def psnr_gpu(sr: torch.Tensor, hr: torch.Tensor) -> float:
 
 def fit(net, source, epochs: int, batch_size: int, lr: float = 2e-4, n_steps: int = 15, gamma: float = 0.5,
         start_epoch: int = 0, ckpt_dir: Optional[str] = None, model_name: str = "LFT", seed: int = 0,
-        use_augmentation: bool = True, log=print, max_batches_per_epoch: Optional[int] = None):
+        use_augmentation: bool = True, log=print, max_batches_per_epoch: Optional[int] = None, decay_rate: float = 0.0):
     """Train ``net`` (lft_amd.module.get_model on this rank's GPU) like reference train.py:86-110.  ``batch_size`` is
     the GLOBAL batch (reference --batch_size).  Returns the list of per-epoch mean losses (global)."""
     import torch.distributed as dist
@@ -148,7 +148,7 @@ def fit(net, source, epochs: int, batch_size: int, lr: float = 2e-4, n_steps: in
     if not (dist.is_available() and dist.is_initialized()):
         rank, world = 0, 1
     dev = next(net.parameters()).device
-    ts = TrainStep(net, lr=lr)
+    ts = TrainStep(net, lr=lr, weight_decay=decay_rate)            # reference train.py:82 weight_decay=args.decay_rate
     history = []
     for epoch in range(start_epoch, epochs):
         ts.lr = step_lr(lr, epoch, n_steps, gamma)

@@ -12,6 +12,7 @@ from lft_amd.params import deterministic_state, synthetic_lr
 from oracle import lft_oracle as O
 
 pytestmark = pytest.mark.gpu
+BF16_END_TO_END = 2.5e-3      # max|err| / max|ref| of the bf16 throughput path (operand rounding; see tests/diag_precision_study.py)
 GOLDEN = ["tiny_a5_s2_b2_6x6", "small_a5_s4_b1_8x8", "small_a9_s4_b1_8x8", "rect_a5_s2_b1_8x6", "wide_a2_s2_b1_6x12", "cfg1_a5_s2_b1_32x32", "cfg2_a5_s4_b1_32x32"]
 
 
@@ -36,7 +37,9 @@ def test_forward_matches_reference_fixture(name, precision, golden_dir):
     rel = float((out - ref).abs().max() / ref.abs().max())
     print(f"{name} [{precision}] rel max err {rel:.3e}  psnr(ours, reference) {O.psnr(out, ref):.2f} dB")
     assert out.shape == ref.shape
-    assert rel <= (1e-3 if precision == "fp32" else 5e-3)          # north_star: 1e-3 relative on the fp32 path
+    # north_star: 1e-3 relative -- met by the fp32 path (observed 3e-7).  The bf16 path rounds every MFMA operand and every
+    # inter-kernel tensor to 8 significant bits: 1.5e-3 .. 1.9e-3 observed, which does NOT meet 1e-3; its gate only pins that level.
+    assert rel <= (1e-3 if precision == "fp32" else BF16_END_TO_END)
     assert O.psnr(out, ref) >= (100.0 if precision == "fp32" else 55.0)
 
 
@@ -75,7 +78,7 @@ def test_full_size_properties_cfg4_cfg5(A, s, B, h, w):
         y32 = ref32(lr[:1])
     rel = float((full[:1] - y32).abs().max() / y32.abs().max())
     print(f"A{A} {h}x{w}: bf16 vs fp32 path rel max {rel:.2e}")
-    assert rel <= 5e-3
+    assert rel <= BF16_END_TO_END
     with torch.no_grad():
         dict(ref32.named_parameters())["upsampling.3.weight"].zero_()
         skip_only = ref32(lr[:1])
@@ -150,3 +153,24 @@ def test_pipelined_forward_matches_plain_forward():
     for i, y in outs:
         assert torch.equal(y, ref[i]), i
     assert sorted(i for i, _ in outs) == [0, 1, 2, 3, 4]
+
+
+def test_graph_refuses_replay_after_weights_change():
+    """A captured forward has the packed-weight buffer's address baked in; once the weights are re-packed or dropped
+    (optimizer step, load_state_dict) a replay must fail loudly instead of reading freed memory."""
+    from lft_amd.module import GraphedForward
+    A, s, B, h, w = 2, 2, 1, 8, 8
+    net = make_net(A, s, 1, "default", "bf16")
+    lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=0)).to("cuda:0")
+    with torch.no_grad():
+        g = GraphedForward(net, lr)
+        a = g(lr).clone()
+        assert torch.equal(a, net(lr))
+        with torch.no_grad():
+            next(net.parameters()).mul_(1.5)          # in-place change: the next forward re-packs into a new buffer
+        b = net(lr)
+        assert not torch.equal(a, b)
+        with pytest.raises(RuntimeError):
+            g(lr)
+        g2 = GraphedForward(net, lr)
+        assert torch.equal(g2(lr), b)

@@ -4,7 +4,8 @@ against the fixtures captured from the real reference.
 
 Tolerances (BASELINE.json north_star: 1e-3 relative fp32):
   fp32 path : max|err| <= 1e-4 * max|ref| per stage (observed ~1e-6), <= 1e-3 * max|ref| required end to end
-  bf16 path : rms err <= 1e-2 * rms(ref) per stage; end to end reported and bounded at 5e-3 * max|ref|
+  bf16 path : rms err <= 1e-2 * rms(ref) per stage; end to end bounded at 2.5e-3 * max|ref| (observed 1.5e-3 .. 1.9e-3: bf16 operand
+              rounding, tests/diag_precision_study.py -- this path does NOT meet the 1e-3 of north_star; the fp32 path does)
 """
 import os
 
@@ -151,6 +152,6 @@ def test_forward_vs_oracle(case, prec):
     got, ref = out.cpu(), case["out"]
     msg = f"forward [{prec}] " + G.err_report(got, ref) + f" psnr={O.psnr(got, ref):.2f}dB"
     print(msg)
-    assert G.rel_max(got, ref) <= (1e-3 if prec == "fp32" else 5e-3), msg
+    assert G.rel_max(got, ref) <= (1e-3 if prec == "fp32" else 2.5e-3), msg
     res_got, res_ref = got - case["taps"]["skip"], case["taps"]["res"]
     assert G.rel_rms(res_got, res_ref) <= (1e-4 if prec == "fp32" else 2e-2), "residual branch: " + G.err_report(res_got, res_ref)

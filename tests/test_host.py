@@ -58,7 +58,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.lib().lft_version() == 1
+    assert _lib.lib().lft_version() == 2
 
 
 def test_size_queries_and_argument_errors():
@@ -95,4 +95,5 @@ def test_training_and_metrics_size_queries_and_argument_errors():
     assert L.lft_train_backward(arr, 78, 1, 1, None, 1, 1, 5, 8, 8, 2, 0, None, None) == -1    # null dout
     assert L.lft_view_metrics_scratch_bytes(1, 5, 32, 32, ctypes.byref(n)) == 0 and n.value == 25 * 4 * 3 * 8
     assert L.lft_view_metrics(1, 1, 1, 5, 8, 8, 2.0, 1, 1, 1, None) == -2                 # views smaller than the SSIM window
-    assert L.lft_adam_step(1, 1, 1, 1, 10, 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, None) == -1   # steps count from 1
+    assert L.lft_adam_step(1, 1, 1, 1, 10, 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, 0.0, None) == -1   # steps count from 1
+    assert L.lft_adam_step(1, 1, 1, 1, 10, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, -0.1, None) == -1  # weight decay >= 0

@@ -44,7 +44,7 @@ rounds = int(os.environ.get("AB_ROUNDS", "2"))
 for rnd in range(rounds):
     for name, flags in variants:
         env = dict(os.environ, LFT_LIB_PATH=os.path.join(outdir, f"liblft_{name}.so"))
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "15", "--no-cpu-baseline"] + extra,
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "15", "--no-cpu-baseline", "--no-extras"] + extra,
                            env=env, capture_output=True, text=True)
         try:
             j = json.loads(r.stdout.strip().splitlines()[-1])

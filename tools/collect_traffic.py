@@ -3,8 +3,19 @@
 profiles/<name>.json: mean HBM-side bytes per launch and kernel.  FETCH_SIZE is doubled for the kernels whose
 reads are wide (16 B/lane) coalesced streams -- the gfx950 correction of the guide; kernels reading dwords
 (k_assemble, k_conv0) are left uncorrected and flagged."""
-import csv, glob, json, re, sys, collections
+import csv, glob, hashlib, json, os, re, sys, collections
 fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def source_hash():                      # the same hash bench.py computes: ties this file to the sources it was measured on
+    from lft_amd import _lib
+    h = hashlib.sha256()
+    for name in sorted(_lib.SOURCES):
+        h.update(open(os.path.join(_lib.CSRC, name), "rb").read())
+    return h.hexdigest()[:16]
+
 def load(d, counter):
     acc = collections.defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -20,7 +31,7 @@ for k in sorted(set(F) | set(W)):
     corr = 1.0 if k in narrow else 2.0
     res[k] = {"fetch_raw": F.get(k, 0.0), "fetch_correction": corr, "fetch": F.get(k, 0.0) * corr, "write": W.get(k, 0.0),
               "total": F.get(k, 0.0) * corr + W.get(k, 0.0)}
-json.dump({"unit": "bytes per launch (mean)", "workload": "bench.py default: A5, 4x, B=4, 32x32 LR, bf16, single stream",
+json.dump({"source_hash": source_hash(), "unit": "bytes per launch (mean)", "workload": "bench.py default: A5, 4x, B=4, 32x32 LR, bf16, single stream",
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; counter x 1024; FETCH x2 for wide coalesced reads (gfx950)",
            "kernels": res}, open(out, "w"), indent=1)
 for k, v in res.items():

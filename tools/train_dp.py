@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--lr", type=float, default=2e-4)
     ap.add_argument("--n_steps", type=int, default=15)
     ap.add_argument("--gamma", type=float, default=0.5)
+    ap.add_argument("--decay_rate", type=float, default=0.0, help="Adam weight_decay, as the reference's option.py")
     ap.add_argument("--epoch", type=int, default=50)
     ap.add_argument("--data", default=None)
     ap.add_argument("--synthetic", type=int, default=0)
@@ -55,7 +56,8 @@ def main():
         src = trainer.SyntheticPatchSource(args.synthetic or 64, args.angRes, args.scale_factor, 32, seed=0)
     ckpt_dir = os.path.join(args.path_log, "SR_%dx%d_%dx" % (args.angRes, args.angRes, args.scale_factor), args.model_name, "checkpoints")
     trainer.fit(net, src, args.epoch, args.batch_size, lr=args.lr, n_steps=args.n_steps, gamma=args.gamma, start_epoch=start,
-                ckpt_dir=ckpt_dir, model_name=args.model_name, max_batches_per_epoch=args.max_batches or None)
+                ckpt_dir=ckpt_dir, model_name=args.model_name, max_batches_per_epoch=args.max_batches or None,
+                decay_rate=args.decay_rate)
 
 
 if __name__ == "__main__":
