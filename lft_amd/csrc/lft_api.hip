@@ -186,6 +186,17 @@ int run_pack(std::vector<PackOp>& ops, T* dst, int expect_frags, hipStream_t st)
     return 0;
 }
 
+#ifndef LFT_TOKLM
+#define LFT_TOKLM 1
+#endif
+#ifndef LFT_YLM
+#define LFT_YLM 1
+#endif
+// Lane-major hand-off of the spatial tokens from k_spa1 to part B: every workgroup tile of k_spa1 must be full, and the bf16
+// consumer (k_spa_b, 8 x 4 blocks) additionally needs a tile to be 32 columns of ONE image row.
+template <typename T> bool tok_lane_major(const Dims& d) {
+    return LFT_TOKLM && d.hw % (32 * kNwSpa1) == 0 && (sizeof(T) == 4 || d.w % 32 == 0);
+}
 // k_spa1 launch with the ring chunk size that fits best: 16-fragment chunks if two workgroups then still share a CU
 // (<= 80 KiB each) or if they are the only ones fitting at all... else 8-fragment chunks (wide views, fp32).
 template <typename T, bool PE_ONLY>
@@ -195,13 +206,7 @@ int launch_spa1(unsigned nwg, const T* in, const T* ws, const float* ln, const T
     const size_t share = kMaxLds / LFT_SPA_OCC;                           // LDS per workgroup if LFT_SPA_OCC of them share a CU
     const bool use8 = (l16 > share && l8 <= share) || l16 > kMaxLds;
     int rc;
-#ifndef LFT_TOKLM
-#define LFT_TOKLM 1
-#endif
-#ifndef LFT_YLM
-#define LFT_YLM 1
-#endif
-    const bool lm = LFT_TOKLM && !PE_ONLY && sizeof(T) == 4 && d.hw % (32 * kNwSpa1) == 0;      // fp32, full tiles everywhere: hand the token tile to k_spa2 in lane-major form (bf16: k_spa_b reads row-major 8 x 4 blocks)
+    const bool lm = !PE_ONLY && tok_lane_major<T>(d);      // hand the token tile to part B in lane-major tile form
 #define LFT_LAUNCH_SPA1(CHV, LMV, LDSV)                                                                                     \
     do {                                                                                                                    \
         if ((rc = allow_lds(k_spa1<T, PE_ONLY, CHV, LMV>, LDSV, "k_spa1"))) return rc;                                      \
@@ -362,13 +367,16 @@ int spa_part_b(const void* packed, const PackedLayout& L, int l, const T* skip, 
         // bf16: windowed attention + out_proj + FFN + 1x1x1 conv in ONE kernel (the attention output stays in registers)
         const unsigned ntile = (unsigned)(nimg * ((d.h + kAttTY - 1) / kAttTY) * ((d.w + kAttTX - 1) / kAttTX));
         const size_t lds = kSpaBLds;
-        if (skip) {
-            if ((rc = allow_lds(k_spa_b<true>, lds, "k_spa_b"))) return rc;
-            k_spa_b<true><<<ntile, 256, lds, st>>>(tok, q, k, v, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.h, d.w);
-        } else {
-            if ((rc = allow_lds(k_spa_b<false>, lds, "k_spa_b"))) return rc;
-            k_spa_b<false><<<ntile, 256, lds, st>>>(tok, q, k, v, at<T>(packed, L.s_spa2[l]), ln, nullptr, out, d.h, d.w);
-        }
+#define LFT_LAUNCH_SPAB(SKV, LMV, YLV)                                                                                      \
+    do {                                                                                                                    \
+        if ((rc = allow_lds(k_spa_b<SKV, LMV, YLV>, lds, "k_spa_b"))) return rc;                                            \
+        k_spa_b<SKV, LMV, YLV><<<ntile, 256, lds, st>>>(tok, q, k, v, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.h, d.w); \
+    } while (0)
+        const bool tlm = tok_lane_major<T>(d);
+        if (out_lm && !(skip && tlm)) return fail(LFT_ERR_ARG, "internal: lane-major output needs the skip variant and lane-major tokens");
+        if (skip) { if (out_lm) LFT_LAUNCH_SPAB(true, true, true); else if (tlm) LFT_LAUNCH_SPAB(true, true, false); else LFT_LAUNCH_SPAB(true, false, false); }
+        else { if (tlm) LFT_LAUNCH_SPAB(false, true, false); else LFT_LAUNCH_SPAB(false, false, false); }
+#undef LFT_LAUNCH_SPAB
         LFT_LAUNCH_OK("k_spa_b");
         return 0;
     } else {
@@ -380,7 +388,7 @@ int spa_part_b(const void* packed, const PackedLayout& L, int l, const T* skip, 
                                                                      nullptr, nullptr, nullptr, nullptr, nullptr, d.h, d.w, 128);
     LFT_LAUNCH_OK("k_spa_attn");
     const unsigned nb = blocks_for(d.ntok, 32 * kNwSpa2);
-    const bool lm = LFT_TOKLM && sizeof(T) == 4 && d.hw % (32 * kNwSpa1) == 0;      // must match launch_spa1's choice
+    const bool lm = tok_lane_major<T>(d);      // must match launch_spa1's choice
 #define LFT_LAUNCH_SPA2(SKV, LMV, YLV)                                                                                      \
     do {                                                                                                                    \
         if ((rc = allow_lds(k_spa2<T, SKV, LMV, YLV>, lds_spa2<T>(), "k_spa2"))) return rc;                                 \
@@ -432,10 +440,10 @@ int forward_impl(const void* packed, const float* lr, float* out, void* ws, cons
     for (int l = 0; l < kLayers; ++l) {                  // angular first, then spatial (reference LFT.py:249-250)
         if ((rc = ang_block<T>(packed, L, l, cur, xa, d, st))) return rc;
         const bool last = l == kLayers - 1;                  // its output only feeds the up-sampler: same 32-token tiling, lane-major tiles
-        if ((rc = spa_block<T>(packed, L, l, xa, last ? feat : nullptr, xb, ws, W, d, st, last && LFT_TOKLM && LFT_YLM && sizeof(T) == 4 && d.hw % (32 * kNwSpa1) == 0))) return rc;
+        if ((rc = spa_block<T>(packed, L, l, xa, last ? feat : nullptr, xb, ws, W, d, st, last && LFT_YLM && tok_lane_major<T>(d)))) return rc;
         cur = xb;
     }
-    return upsample<T>(packed, L, xb, lr, out, ws, W, d, st, LFT_TOKLM && LFT_YLM && sizeof(T) == 4 && d.hw % (32 * kNwSpa1) == 0);
+    return upsample<T>(packed, L, xb, lr, out, ws, W, d, st, LFT_YLM && tok_lane_major<T>(d));
 }
 
 // Mean duration of ONE kernel of the forward, launched `reps` times back to back between two HIP events on `stream` (no

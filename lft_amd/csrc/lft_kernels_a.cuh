@@ -98,9 +98,9 @@ __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, con
     float wr[72];
 #pragma unroll
     for (int i = 0; i < 72; ++i) wr[i] = w0[cg * 72 + i];
-    const long long ntok = (long long)B * V * hw;
-    for (long long t = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); t < ntok; t += (long long)gridDim.x * 32) {
-        const int im = (int)(t / hw), p = (int)(t - (long long)im * hw);
+    const int ntok = B * V * hw;                                      // < 2^27 (make_dims): 32-bit index math (64-bit divisions cost more than the conv)
+    for (int t = blockIdx.x * 32 + (threadIdx.x >> 3); t < ntok; t += gridDim.x * 32) {
+        const int im = t / hw, p = t - im * hw;
         const int b = im / V, v = im - b * V;
         const int y = p / w, x = p - y * w, a1 = v / A, a2 = v - a1 * A;
         const float* img = lr + (size_t)b * (A * h) * (A * w) + (size_t)(a1 * h) * (A * w) + a2 * w;

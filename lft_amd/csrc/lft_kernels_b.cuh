@@ -208,14 +208,26 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa2(const T* __restri
 #ifndef LFT_SPAB_TWOPASS
 #define LFT_SPAB_TWOPASS 0
 #endif
-constexpr int kSpaBChunk = 8, kSpaBSlots = 6;
+#ifndef LFT_SPAB_CHUNK
+#define LFT_SPAB_CHUNK 8
+#endif
+constexpr int kSpaBChunk = LFT_SPAB_CHUNK;                     // fragments per ring chunk in phase B
 constexpr int kAdTile = kAttHR * kAttHC * 64;                 // one tensor's halo tile in LDS: 8 x 36 tokens x 64 B
 constexpr int kAdPerWave = 2 * kAdTile / 1024 / 4;            // LDS-DMA pieces per wave and head pair (9)
 static_assert(2 * kAdTile == 4 * kAdPerWave * 1024, "the K and V tiles must split into whole pieces over 4 waves");
 constexpr int kSpaBLds = 4 * kAdTile + 1024;                  // two K+V buffers + LayerNorm parameters
-// phase B re-uses the two K / V buffers: ring slots 0..3 in buffer A, slots 4,5 and the tile I/O scratch in buffer B
-static_assert(4 * kSpaBChunk * 1024 <= 2 * kAdTile, "ring slots 0..3 must fit buffer A");
-static_assert(2 * kSpaBChunk * 1024 + 4 * TileIO<4, bf16_t>::BYTES <= 2 * kAdTile, "ring slots 4,5 + scratch must fit buffer B");
+// Phase B re-uses the two K / V buffers (36 KiB each): ring slots 0 .. kSpaBSlotsA-1 in buffer A, the others in buffer B from
+// its start; the tile I/O scratch sits 16 KiB into buffer B -- behind the slots there (8-fragment chunks), or on top of the
+// LAST slot (16-fragment chunks), which is not filled before every wave has passed the first ring barrier (TOK tile loaded)
+// and has had its last chunk consumed well before the final store.
+constexpr int kSpaBSlotsA = (2 * kAdTile) / (kSpaBChunk * 1024);
+constexpr int kSpaBSlotsB = kSpaBChunk == 8 ? 2 : 2 * kAdTile / (kSpaBChunk * 1024);
+constexpr int kSpaBSlots = kSpaBSlotsA + kSpaBSlotsB;
+constexpr int kSpaBScratchOfs = 16384;
+static_assert(kSpaBChunk == 8 || kSpaBChunk == 16, "phase-B ring chunk: 8 or 16 fragments");
+static_assert(kSpaBScratchOfs + 4 * TileIO<4, bf16_t>::BYTES <= 2 * kAdTile, "scratch must fit buffer B");
+static_assert(kSpaBChunk == 8 ? kSpaBSlotsB * kSpaBChunk * 1024 <= kSpaBScratchOfs : (kSpaBSlotsB - 1) * kSpaBChunk * 1024 <= kSpaBScratchOfs,
+              "scratch may only overlap the last ring slot");
 
 // Two 16-byte query fragments of one head pair, loaded by inline asm so that hipcc neither counts them nor drains the
 // LDS-DMA in flight when they are used (it waits vmcnt(0) for ordinary loads while a global_load_lds is outstanding).
@@ -228,7 +240,7 @@ template <int N> LFT_DEV void wait_vm_q(raw16& a, raw16& b) {          // s_wait
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool SKIP>
+template <bool SKIP, bool TOKLM = false, bool YLM = false>   // TOKLM: k_spa1 wrote the tokens as lane-major 32-token tiles (w % 32 == 0: a tile = 32 columns of one image row); YLM: write the output so (consumer: k_up)
 __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK, const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                   const bf16_t* __restrict__ Vv, const bf16_t* __restrict__ ws, const float* __restrict__ ln,
                                                   const bf16_t* __restrict__ skip, bf16_t* __restrict__ Y, int h, int w) {
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
     stage(0, bufA);
     stage(1, bufB);
     Ring ring;
-    ring.setup(ws, smem, 176, 4, 2 * kAdTile - 4 * kSpaBChunk * 1024);
+    ring.setup(ws, smem, 176, kSpaBSlotsA, 2 * kAdTile - kSpaBSlotsA * kSpaBChunk * 1024);
     // this wave's block of tokens in memory (clamped origin: readable even when the block lies outside the image)
     BlkRows rows;
     rows.nrow = max(0, min(4, h - y0)); rows.ncol = max(0, min(8, w - (x0 + bxl)));
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
         char* const buf = (hg & 1) ? bufB : bufA;
         if (hg == 0) { wait_vm_q<0>(qa, qb); params_store(lds_ln, 256, lnv); }
         else if (hg < 3) wait_vm_q<kAdPerWave>(qa, qb);
-        else wait_vm_q<4 * Ring::PIECES_PER_WAVE>(qa, qb);
+        else wait_vm_q<kSpaBSlotsA * Ring::PIECES_PER_WAVE>(qa, qb);
         wg_barrier_keep_vm();                                              // everybody's pieces of this head pair have landed
         LFT_STAMP(18 + 2 * hg);
         Frag<T> qf[2];
@@ -414,12 +426,29 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
         wg_barrier_keep_vm();                                              // every wave is done reading this buffer
         if (hg < 3) q_load_async(qptr + 32 * (hg + 1), qptr + 32 * (hg + 1) + 16, qa, qb);
         if (hg < 2) stage(hg + 2, buf);
-        else if (hg == 2) { ring.issue(0); ring.issue(1); ring.issue(2); ring.issue(3); }      // buffer A now belongs to the weight ring
-        else ring.issue(4);                                                                    // ... and so does buffer B
+        else if (hg == 2) {                                                // buffer A now belongs to the weight ring
+#pragma unroll
+            for (int c = 0; c < kSpaBSlotsA; ++c) ring.issue(c);
+        } else {                                                           // ... and so does buffer B
+#pragma unroll
+            for (int c = kSpaBSlotsA; c < kSpaBSlots - 1; ++c) ring.issue(c);
+        }
     }
-    char* scr = bufB + 2 * kSpaBChunk * 1024 + wave * TileIO<4, T>::BYTES;
+    char* scr = bufB + kSpaBScratchOfs + wave * TileIO<4, T>::BYTES;
     f32x16 t[4], n[4];
-    {
+    if constexpr (TOKLM) {
+        // Row rr of this wave's 8 x 4 block = lanes 8 wave .. 8 wave + 7 of the lane-major tile of image row y0 + rr: the 16-byte
+        // piece [k-step][32 hh + column] holds exactly registers 8k .. 8k+7 of this lane's accumulator tile (load_tile_lm),
+        // so the token tile arrives with eight 16-byte loads per lane and no LDS transposition.
+        const int ty_ = min(y0 + (r >> 3), h - 1);
+        const bf16_t* src = TOK + (img0 + (long long)ty_ * w + x0) * 128 + (32 * hh + bxl + (r & 7)) * 8;
+#pragma unroll
+        for (int kidx = 0; kidx < 8; ++kidx) {
+            const bf16x8 v = __builtin_bit_cast(bf16x8, load_raw16(reinterpret_cast<const char*>(src + kidx * 512)));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[kidx >> 1][8 * (kidx & 1) + j] = (float)v[j];
+        }
+    } else {
         BlkRows rt = rows; rt.img_row_bytes = w * 256; rt.tok_bytes = 256;
         load_tile_map<4, T>(TOK + tok0 * 128, rt, lane, t, scr);
     }
@@ -457,7 +486,20 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) y[nt] += sk[nt];
     }
-    store_tile_map<2, T>(Y + tok0 * 64, ry, lane, y, scr);
+    if constexpr (YLM) {                                              // the mirror image of the TOKLM load: four 16-byte stores per lane, no LDS
+        if (qy < h) {
+            bf16_t* dst = Y + (img0 + (long long)qy * w + x0) * 64 + (32 * hh + bxl + (r & 7)) * 8;
+#pragma unroll
+            for (int kidx = 0; kidx < 4; ++kidx) {
+                bf16x8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (bf16_t)y[kidx >> 1][8 * (kidx & 1) + j];
+                store_raw16(reinterpret_cast<char*>(dst + kidx * 512), __builtin_bit_cast(raw16, v));
+            }
+        }
+    } else {
+        store_tile_map<2, T>(Y + tok0 * 64, ry, lane, y, scr);
+    }
     LFT_STAMP(30);
 }
 
