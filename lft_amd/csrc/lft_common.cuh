@@ -217,22 +217,13 @@ struct WRing {
     const char* g;
     char* lds;
     int lane, wave, pos, nfrag;
-    // Exact accounting of VM operations younger than the chunk being published (stores count in vmcnt and take
-    // microseconds to be acknowledged; forcing them complete at every chunk barrier cost more than the MFMAs).
-    // A kernel may note_vm(n) the wave-level VM instructions it issued since the last chunk barrier -- only when
-    // they are certain to have been issued (`exact` = every tile of the workgroup is full, so no predicated store
-    // is skipped).  Under-counting is always safe (the wait only gets stricter); over-counting is not.
-    int vm_cur, vm_prev;
-    bool exact;
-    LFT_MEM void init(const T* stream, char* lds_base, int total_frags, bool exact_counts = false) {
+    LFT_MEM void init(const T* stream, char* lds_base, int total_frags) {
         g = reinterpret_cast<const char*>(stream); lds = lds_base; nfrag = total_frags; pos = 0;
         lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        vm_cur = 0; vm_prev = 0; exact = exact_counts;
         issue(0);
         issue(1);
     }
-    LFT_MEM void note_vm(int n) { vm_cur += n; }
     // Every wave issues exactly PIECES_PER_WAVE DMA instructions per chunk (clamped to the last piece of the
     // stream when the chunk is short) so that the counted wait below is exact.
     LFT_MEM void issue(int c) {
@@ -246,14 +237,12 @@ struct WRing {
             glds_piece(src + piece * 1024, dst + piece * 1024, lane);
         }
     }
-    // Chunk c's DMA was issued right after barrier c-2.  Younger than it: the VM ops noted in the two intervals
-    // since, and the DMA of chunk c+1 (if it exists).
-    LFT_MEM void wait_landed(bool next_in_flight) {
-        const int base = next_in_flight ? PIECES_PER_WAVE : 0;
-        if (exact) wait_vmcnt(base + vm_prev + vm_cur);
-        else wait_vmcnt(base);
-        vm_prev = vm_cur; vm_cur = 0;
-    }
+    // Chunk c's DMA was issued right after barrier c-2; the only operations this wait may leave in flight are the
+    // PIECES_PER_WAVE pieces of chunk c+1, the youngest DMA.  Any other VM operation the kernel has issued since (tile
+    // stores, loads) is younger still and only makes the wait stricter -- never unsafe.  (Round 1 also subtracted the
+    // kernel's own store counts to let stores stay in flight; that relied on hipcc emitting exactly the counted number of
+    // store instructions, failed once the stores changed form, and bought nothing measurable: removed.)
+    LFT_MEM void wait_landed(bool next_in_flight) { wait_vmcnt(next_in_flight ? PIECES_PER_WAVE : 0); }
     LFT_MEM Frag<T> next() {
         const int c = pos / CH, i = pos % CH;
         if (i == 0) {
@@ -424,7 +413,7 @@ LFT_DEV void store_lane_major(T* __restrict__ tile_base, int lane, const f32x16 
 }
 // The same layout for an ACTIVATION tile that one kernel writes and another reads with the same 32-token tiling
 // (the spatial tokens between k_spa1 and k_spa2): 16 bytes per lane and store, no LDS transposition on either side.
-// Returns the number of wave-level store instructions (for WRing::note_vm).
+// Returns the number of wave-level store instructions.
 template <int NT, typename T>
 LFT_DEV int store_tile_lm(T* __restrict__ tile_base, int lane, const f32x16 (&a)[NT]) {
 #pragma unroll

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
     raw16 lnv = raw16{0u, 0u, 0u, 0u};
     if (!PE_ONLY) lnv = params_load(ln, 256);                         // norm.{weight,bias}; ln is null in the pack-time PE_ONLY launch
     WRing<T, CH, NW> ring;
-    ring.init(ws, smem, PE_ONLY ? 144 : 240, p0 + TT <= hw);
+    ring.init(ws, smem, PE_ONLY ? 144 : 240);
     stage_conv_input<T, NW>(X + (size_t)im * hw * 64, p0, hw, w, lds_in);
     LFT_STAMP(12);
     wait_staged();
@@ -78,8 +78,8 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
     const int t0 = p0 + wave * 32, nvalid = max(0, min(32, hw - t0));
     const size_t tile_off = ((size_t)im * hw + min(t0, hw - 1)) * 128;
     char* scr = lds_in + wave * TileIO<4, T>::BYTES;
-    if constexpr (TOKLM) ring.note_vm(store_tile_lm<4, T>(TOK + ((size_t)im * hw + t0) * 128, lane, t));   // hw % (32 NW) == 0: every tile is full
-    else ring.note_vm(store_tile<4, T>(TOK + tile_off, nvalid, lane, t, scr));
+    if constexpr (TOKLM) store_tile_lm<4, T>(TOK + ((size_t)im * hw + t0) * 128, lane, t);   // hw % (32 NW) == 0: every tile is full
+    else store_tile<4, T>(TOK + tile_off, nvalid, lane, t, scr);
     LFT_STAMP(4);
     Frag<T> nf[8];
     // Each projection is produced and stored in two 64-channel halves: 32 accumulator registers instead of 64
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
         f32x16 a[2];
         zero_acc<2>(a);
         linear_ring<2, 8, T>(ring, nf, a);
-        if constexpr (QKVLM) ring.note_vm(store_tile_lm<2, T>(Vv + lm_off + half * 2048, lane, a));
-        else ring.note_vm(store_tile<2, T, 128>(Vv + tile_off + 64 * half, nvalid, lane, a, scr));
+        if constexpr (QKVLM) store_tile_lm<2, T>(Vv + lm_off + half * 2048, lane, a);
+        else store_tile<2, T, 128>(Vv + tile_off + 64 * half, nvalid, lane, a, scr);
     }
     LFT_STAMP(6);
     add_acc_raw<4, T>(t, pe_raw, ok);
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
         f32x16 a[2];
         zero_acc<2>(a);
         linear_ring<2, 8, T>(ring, nf, a);
-        if constexpr (QKVLM) ring.note_vm(store_tile_lm<2, T>(Q + lm_off + half * 2048, lane, a));
-        else ring.note_vm(store_tile<2, T, 128>(Q + tile_off + 64 * half, nvalid, lane, a, scr));
+        if constexpr (QKVLM) store_tile_lm<2, T>(Q + lm_off + half * 2048, lane, a);
+        else store_tile<2, T, 128>(Q + tile_off + 64 * half, nvalid, lane, a, scr);
     }
     LFT_STAMP(9);
 #pragma unroll
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
         f32x16 a[2];
         zero_acc<2>(a);
         linear_ring<2, 8, T>(ring, nf, a);
-        if constexpr (QKVLM) ring.note_vm(store_tile_lm<2, T>(K + lm_off + half * 2048, lane, a));
-        else ring.note_vm(store_tile<2, T, 128>(K + tile_off + 64 * half, nvalid, lane, a, scr));
+        if constexpr (QKVLM) store_tile_lm<2, T>(K + lm_off + half * 2048, lane, a);
+        else store_tile<2, T, 128>(K + tile_off + 64 * half, nvalid, lane, a, scr);
     }
     LFT_STAMP(11);
 }

@@ -35,12 +35,14 @@ extra = os.environ.get("AB_BENCH_ARGS", "").split()
 if os.environ.get("AB_TEST"):
     for name, flags in variants:
         env = dict(os.environ, LFT_LIB_PATH=os.path.join(outdir, f"liblft_{name}.so"))
-        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_parity.py", "tests/test_gpu_module.py",
-                            "tests/test_gpu_determinism.py"], env=env, capture_output=True, text=True, cwd=ROOT)
+        targets = os.environ.get("AB_TEST_ARGS", "tests/test_gpu_parity.py tests/test_gpu_module.py tests/test_gpu_determinism.py").split()
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + targets, env=env, capture_output=True, text=True, cwd=ROOT)
         print(f"[test] {name:14s} rc={r.returncode} {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]}", flush=True)
         if r.returncode != 0:
             print(r.stdout[-3000:], flush=True)
 rounds = int(os.environ.get("AB_ROUNDS", "2"))
+if os.environ.get("AB_TEST") == "only":
+    rounds = 0
 for rnd in range(rounds):
     for name, flags in variants:
         env = dict(os.environ, LFT_LIB_PATH=os.path.join(outdir, f"liblft_{name}.so"))
