@@ -341,10 +341,16 @@ int ang_block(const void* packed, const PackedLayout& L, int l, const T* in, T* 
     const int npix = d.B * d.hw;
     const size_t lds = lds_ang<T>();
     int rc;
-    if ((rc = allow_lds(k_ang<T>, lds, "k_ang"))) return rc;
     const unsigned grid = std::min<unsigned>(blocks_for(npix, 4), 256u * (unsigned)std::max<size_t>(1, kMaxLds / lds));
-    k_ang<T><<<grid, 256, lds, st>>>(in, out, at<T>(packed, L.s_ang[l]), at<float>(packed, L.ln_ang[l]),
-                                                   at<float>(packed, L.ang_pe), d.V, d.hw, npix);
+    if (d.V <= 25) {                                                  // 5 x 5 and smaller: score rows 25..31 are never a view
+        if ((rc = allow_lds(k_ang<T, 13>, lds, "k_ang"))) return rc;
+        k_ang<T, 13><<<grid, 256, lds, st>>>(in, out, at<T>(packed, L.s_ang[l]), at<float>(packed, L.ln_ang[l]),
+                                             at<float>(packed, L.ang_pe), d.V, d.hw, npix);
+    } else {
+        if ((rc = allow_lds(k_ang<T, 16>, lds, "k_ang"))) return rc;
+        k_ang<T, 16><<<grid, 256, lds, st>>>(in, out, at<T>(packed, L.s_ang[l]), at<float>(packed, L.ln_ang[l]),
+                                             at<float>(packed, L.ang_pe), d.V, d.hw, npix);
+    }
     LFT_LAUNCH_OK("k_ang");
     return 0;
 }

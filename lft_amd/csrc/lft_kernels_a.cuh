@@ -259,7 +259,10 @@ LFT_DEV void linear_lds(const char* wl, int f0, int lane, const Frag<T> (&x)[KS]
             mma(frag_from_pieces(wl + (f0 + nt * KS + ks) * 1024 * FragInfo<T>::PIECES, lane, T()), x[ks], y[nt]);
 }
 
-template <typename T>
+// NLIVE: accumulator registers 0 .. NLIVE-1 of a score tile can hold an existing view (register i <-> view rows
+// acc_row(i, 0) and acc_row(i, 1)); for V <= 25 (5 x 5) registers 13..15 are rows 25-27 / 29-31, never a view: the
+// softmax skips them at compile time (the kernel is bound by vector-instruction issue, not by the matrix pipe).
+template <typename T, int NLIVE = 16>
 __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ ws,
                                              const float* __restrict__ ln, const float* __restrict__ pe,
                                              int V, int hw, int npix) {
@@ -326,11 +329,13 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
             mma(frag_half(acc_to_frag(k[nt], s, T()), half), acc_to_frag(q[nt], s, T()), S);   // S^T[kv, q]
             float m = S[0];
 #pragma unroll
-            for (int i = 1; i < 16; ++i) m = fmaxf(m, S[i]);
+            for (int i = 1; i < NLIVE; ++i) m = fmaxf(m, S[i]);
             m = xhalf_max(m);
             float sum = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { S[i] = fast_exp2(S[i] - m); sum += S[i]; }
+            for (int i = 0; i < NLIVE; ++i) { S[i] = fast_exp2(S[i] - m); sum += S[i]; }
+#pragma unroll
+            for (int i = NLIVE; i < 16; ++i) S[i] = 0.0f;    // rows that are no view for any lane: probability 0 without computing it
             const float inv = 1.0f / xhalf_sum(sum);
             const bool mine = (r >> 3) == (hd & 3);          // this lane's channel belongs to head hd
 #pragma unroll
