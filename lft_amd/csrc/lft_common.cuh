@@ -746,7 +746,10 @@ LFT_DEV float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
 // as nn.LayerNorm does (reference LFT.py:127,136,199,208).  In place.  gamma/beta may point to LDS (kernels
 // copy the small parameter vectors there at start: a global load in the middle of a kernel would force a
 // vmcnt(0) that also drains the weight ring's in-flight LDS-DMA).
-template <int NT>
+// FAST (bf16 path): v_rsq_f32 / v_rcp_f32 (1 ulp) instead of sqrt + IEEE division (a dozen instructions per token; the
+// kernels that call this are bound by vector-instruction issue).  The fp32 parity path keeps the exact forms.
+LFT_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+template <int NT, bool FAST = false>
 LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* gamma, const float* beta, int h) {
     float s = 0.0f;
 #pragma unroll
@@ -759,7 +762,8 @@ LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* gamma, const float* bet
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { float d = a[nt][i] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(xhalf_sum(q) * (1.0f / (NT * 32)) + LFT_LN_EPS);
+    const float var = xhalf_sum(q) * (1.0f / (NT * 32)) + LFT_LN_EPS;
+    const float rstd = FAST ? __builtin_amdgcn_rsqf(var) : 1.0f / sqrtf(var);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll

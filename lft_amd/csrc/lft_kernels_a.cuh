@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
             for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
             add_acc_raw<2, float>(n, pr, ok);
         }
-        layernorm_acc<2>(n, lds_ln, lds_ln + 64, hh);
+        layernorm_acc<2, sizeof(T) == 2>(n, lds_ln, lds_ln + 64, hh);
         Frag<T> nf[4], xf[4];
         acc_frags<2, T>(n, nf);
         acc_frags<2, T>(x, xf);
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
             for (int i = 0; i < NLIVE; ++i) { S[i] = fast_exp2(S[i] - m); sum += S[i]; }
 #pragma unroll
             for (int i = NLIVE; i < 16; ++i) S[i] = 0.0f;    // rows that are no view for any lane: probability 0 without computing it
-            const float inv = 1.0f / xhalf_sum(sum);
+            const float inv = sizeof(T) == 2 ? fast_rcp(xhalf_sum(sum)) : 1.0f / xhalf_sum(sum);
             const bool mine = (r >> 3) == (hd & 3);          // this lane's channel belongs to head hd
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
         linear_lds<2, 4, T>(smem, 24, lane, of, x);              // t = x + O Wo^T
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
-        layernorm_acc<2>(n, lds_ln + 128, lds_ln + 192, hh);
+        layernorm_acc<2, sizeof(T) == 2>(n, lds_ln + 128, lds_ln + 192, hh);
         acc_frags<2, T>(n, nf);
         f32x16 hid[4];
         zero_acc<4>(hid);

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
     }
     LFT_STAMP(6);
     add_acc_raw<4, T>(t, pe_raw, ok);
-    layernorm_acc<4>(t, lds_ln, lds_ln + 128, hh);
+    layernorm_acc<4, sizeof(T) == 2>(t, lds_ln, lds_ln + 128, hh);
     acc_frags<4, T>(t, nf);
     LFT_STAMP(7);
 #pragma unroll
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
                 __builtin_amdgcn_sched_barrier(0);                         // one score tile at a time (the scheduler would overlap all three again)
             }
             sum = xhalf_sum(sum);
-            const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;                // empty window (h < w quirk): 0, as the pinned reference
+            const float inv = sum > 0.0f ? fast_rcp(sum) : 0.0f;                // empty window (h < w quirk): 0, as the pinned reference
 #else
             f32x16 S[3], o;
             float m = -INFINITY;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { S[j][i] = fast_exp2(S[j][i] - m); sum += S[j][i]; }
             sum = xhalf_sum(sum);
-            const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;                // empty window (h < w quirk): 0, as the pinned reference
+            const float inv = sum > 0.0f ? fast_rcp(sum) : 0.0f;                // empty window (h < w quirk): 0, as the pinned reference
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[i] = 0.0f;
 #pragma unroll
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
     LFT_STAMP(27);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] = t[nt];
-    layernorm_acc<4>(n, lds_ln, lds_ln + 128, hh);
+    layernorm_acc<4, true>(n, lds_ln, lds_ln + 128, hh);
     Frag<T> f[8];
     acc_frags<4, T>(n, f);
 #pragma unroll
