@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 A, S, H, W = 5, 4, 32, 32          # BASELINE.json metric: 5x5 angRes, 32x32 LR, 4x SR (overridable for the other configs)
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 
 
 def flops_per_token(s: int, V: int, wbar: float) -> dict:
@@ -184,23 +184,29 @@ def timed_steps(step, lr, n, warm):
     return time.perf_counter() - t0
 
 
-def parity_path(args, dev, lr, bf16_net):
-    """The exact-fp32 path on the same workload (hipGraph, same steps in flight), and both paths' error on patch 0."""
+def parity_path(args, dev, lr, head_net):
+    """The paths that meet north_star's 1e-3 on the same workload (hipGraph, same steps in flight): fp16 (the bf16 kernels with
+    IEEE-half operands and tensors) and exact fp32; returns their timings and patch-0 outputs for the oracle check."""
     from lft_amd.module import PipelinedForward
     from lft_amd.params import deterministic_state
     from model import LFT
-    net = LFT.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=S), precision="fp32", streams=1)
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in deterministic_state(64, S, seed=1).items()})
-    net = net.to(dev).eval()
-    pipe = PipelinedForward(net, lr, depth=max(1, args.inflight))
-    n = max(10, args.steps // 5)
-    dt = timed_steps(lambda x: pipe(), lr, n, 5)
+    timed, outs = {}, {}
+    for precision, n in (("fp16", max(20, args.steps // 2)), ("fp32", max(10, args.steps // 5))):
+        net = LFT.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=S), precision=precision, streams=1)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in deterministic_state(64, S, seed=1).items()})
+        net = net.to(dev).eval()
+        pipe = PipelinedForward(net, lr, depth=max(1, args.inflight))
+        dt = timed_steps(lambda x: pipe(), lr, n, 10)
+        with torch.no_grad():
+            outs[precision] = net(lr[:1]).float().cpu()
+        timed[precision] = {"value": args.batch * n / dt, "unit": "patches/s", "steps": n, "ms_per_step": dt / n * 1e3}
+        del pipe, net
     with torch.no_grad():
-        out32 = net(lr[:1]).float().cpu()
-        out16 = bf16_net(lr[:1]).float().cpu() if bf16_net is not None else None
-    res = {"precision": "fp32 (v_mfma_f32_32x32x2_f32, fp32 storage)", "value": args.batch * n / dt, "unit": "patches/s", "steps": n,
-           "ms_per_step": dt / n * 1e3, "tolerance": "1e-3 * max|ref| (BASELINE.json north_star)"}
-    return res, out32, out16
+        outs["headline"] = head_net(lr[:1]).float().cpu()
+    res = dict(timed["fp16"], precision="fp16 (v_mfma_f32_32x32x16_f16, fp16 storage, fp32 accumulation / softmax / LayerNorm)",
+               tolerance="1e-3 * max|ref| (BASELINE.json north_star)",
+               exact_fp32=dict(timed["fp32"], precision="fp32 (v_mfma_f32_32x32x2_f32, fp32 storage)"))
+    return res, outs
 
 
 def train_object(dev, math: str):
@@ -245,7 +251,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=4, help="LF patches per GPU per step (BASELINE configs[1]: 4)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--ang", type=int, default=5, help="angular resolution (default: the BASELINE metric's 5)")
     ap.add_argument("--lr", type=int, default=32, help="LR view size (default 32)")
     ap.add_argument("--scale", type=int, default=4, choices=[2, 4])
@@ -338,7 +344,7 @@ def main():
         if dom_ms is None:
             dom_ms, timing = dom_ev_ms, "HIP event after every kernel (lft_forward_profiled)"
         peak = PEAK_TFLOPS[args.precision]
-        bpt = bytes_per_token(S, 2 if args.precision == "bf16" else 4)
+        bpt = bytes_per_token(S, 4 if args.precision == "fp32" else 2)
 
         def roof(k, ms):
             """Roofline of one kernel: the larger of (FLOPs / MFMA peak) and (bytes / HBM peak) names the bound."""
@@ -367,7 +373,7 @@ def main():
                              launch_ms_with_events=dom_ev_ms, launches_per_forward=dom_cnt, gpu_ms_per_forward=total_ms,
                              algorithmic_per_launch={"gflop": fpt[dom] * ntok / 1e9, "gbyte": bpt[dom] * ntok / 1e9},
                              # a fully fused SpaTrans / AngTrans block would read x and write x once
-                             compulsory_gbyte_fused_block=2 * 64 * (2 if args.precision == "bf16" else 4) * ntok / 1e9,
+                             compulsory_gbyte_fused_block=2 * 64 * (4 if args.precision == "fp32" else 2) * ntok / 1e9,
                              kernels={k: dict(ms=round(ms, 4), n=c, **{kk: (round(vv, 3) if isinstance(vv, float) else vv)
                                                                          for kk, vv in roof(k, ms).items() if kk in ("bound", "achieved", "frac")})
                                       for k, (ms, c) in kb.items()}),
@@ -375,20 +381,21 @@ def main():
         tr = result["roofline"].get("traffic")
         if tr:
             result["roofline"]["wasted_traffic_ratio_vs_kernel_contract"] = tr / (bpt[dom] * ntok)
-        out32 = out16 = None
+        outs = None
         if world == 1 and not args.no_extras and args.precision == "bf16":
-            note("timing the exact-fp32 parity path ...")
-            result["parity_path"], out32, out16 = parity_path(args, dev, lr, net)
+            note("timing the fp16 and exact-fp32 parity paths ...")
+            result["parity_path"], outs = parity_path(args, dev, lr, net)
             note("timing the training step (BASELINE configs[2] shape) ...")
             result["train"] = train_object(dev, "fp32")
             result["train"]["bf16x3"] = {k: v for k, v in train_object(dev, "bf16x3").items() if k in ("ms_per_step", "patches_per_s", "algorithmic_tflops")}
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle on host cores ...")
             result["cpu_baseline"], ref = cpu_baseline(args.cpu_seconds, lr[:1].cpu())
-            if out32 is not None:                                       # the oracle as the checker of both paths (patch 0)
+            if outs is not None:                                        # the oracle as the checker of all three paths (patch 0)
                 den = float(ref.abs().max())
-                result["parity_path"]["rel_max_err_vs_oracle"] = float((out32 - ref).abs().max()) / den
-                result["parity_path"]["headline_path_rel_max_err_vs_oracle"] = float((out16 - ref).abs().max()) / den
+                result["parity_path"]["rel_max_err_vs_oracle"] = float((outs["fp16"] - ref).abs().max()) / den
+                result["parity_path"]["exact_fp32"]["rel_max_err_vs_oracle"] = float((outs["fp32"] - ref).abs().max()) / den
+                result["parity_path"]["headline_path_rel_max_err_vs_oracle"] = float((outs["headline"] - ref).abs().max()) / den
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

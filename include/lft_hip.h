@@ -15,8 +15,10 @@
  *  - Return value: 0 ok; <0 argument error (LFT_ERR_*); >0 a hipError_t.  lft_last_error() gives a
  *    thread-local message.  Nothing is thrown across the boundary.
  *  - prec selects the MFMA operand type: LFT_PREC_F32 = exact fp32 (v_mfma_f32_32x32x2_f32),
- *    LFT_PREC_BF16 = bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16).  Activations between
- *    kernels are stored in the same type (float or __bf16, channels-last [B, A*A, h, w, C]).
+ *    LFT_PREC_BF16 = bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16), LFT_PREC_F16 = IEEE half operands /
+ *    fp32 accumulate (v_mfma_f32_32x32x16_f16: same kernels, layouts and speed as bf16, 11 significant bits instead
+ *    of 8, but a range of 65504 -- activations beyond it become inf, which the caller sees in the output).
+ *    Activations between kernels are stored in the same type (float, __bf16 or _Float16, channels-last [B, A*A, h, w, C]).
  *  - Shapes: A = angRes (A*A <= 128 views; 5x5 and 9x9 are the tested ones), h x w = LR view size, s = scale factor (2 or 4),
  *    channels fixed to 64 (reference option.py --channels default, LFT.py:11).
  */
@@ -32,6 +34,7 @@ extern "C" {
 #define LFT_ABI_VERSION 2
 #define LFT_PREC_F32 0
 #define LFT_PREC_BF16 1
+#define LFT_PREC_F16 2
 #define LFT_NUM_PARAMS 78
 /* GEMM arithmetic of the training step: exact fp32 MFMA, or fp32 operands split into bf16 hi + lo with three bf16
  * MFMAs per product (~2^-16 relative per product, 5x the matrix-pipe rate).  Forward and backward of one step must

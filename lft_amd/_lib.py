@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LFT_LIB_PATH") or os.path.join(HERE, "liblft_hip.so")   # LFT_LIB_PATH: experiment builds (tools/ab_build.py)
 SOURCES = ["lft_api.hip", "lft_common.cuh", "lft_kernels_a.cuh", "lft_kernels_b.cuh", "lft_train.cuh", "lft_train_host.cuh", "lft_metrics.cuh"]
 
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 MATH_F32, MATH_BF16X3 = 0, 1
 NUM_PARAMS = 78
 

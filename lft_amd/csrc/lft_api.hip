@@ -56,6 +56,12 @@ inline void prof_mark(const char* name) {
     } while (0)
 
 constexpr int kLayers = 4;   // reference LFT.py:15
+
+// Run `expr` with T bound to the element type of precision `prec` (validated by make_dims beforehand).
+#define LFT_BY_PREC(prec, ...)                                                                \
+    ((prec) == LFT_PREC_F32    ? ([&] { using T = float; return __VA_ARGS__; })()            \
+     : (prec) == LFT_PREC_BF16 ? ([&] { using T = bf16_t; return __VA_ARGS__; })()           \
+                               : ([&] { using T = f16_t; return __VA_ARGS__; })())
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Dims {
@@ -64,7 +70,8 @@ struct Dims {
 };
 
 int make_dims(int B, int A, int h, int w, int s, int prec, Dims* d) {
-    if (prec != LFT_PREC_F32 && prec != LFT_PREC_BF16) return fail(LFT_ERR_ARG, "prec must be LFT_PREC_F32 or LFT_PREC_BF16, got %d", prec);
+    if (prec != LFT_PREC_F32 && prec != LFT_PREC_BF16 && prec != LFT_PREC_F16)
+        return fail(LFT_ERR_ARG, "prec must be LFT_PREC_F32, LFT_PREC_BF16 or LFT_PREC_F16, got %d", prec);
     if (B < 1 || A < 1 || h < 1 || w < 1) return fail(LFT_ERR_SHAPE, "B, A, h, w must be positive (B=%d A=%d h=%d w=%d)", B, A, h, w);
     if (s != 2 && s != 4) return fail(LFT_ERR_SHAPE, "scale factor must be 2 or 4, got %d", s);
     if (A * A > 128) return fail(LFT_ERR_UNSUPPORTED, "angRes %d (A*A=%d views > 128) is not implemented in this build", A, A * A);
@@ -377,8 +384,8 @@ int spa_part_b(const void* packed, const PackedLayout& L, int l, const T* skip, 
         const size_t lds = kSpaBLds;
 #define LFT_LAUNCH_SPAB(SKV, LMV, YLV)                                                                                      \
     do {                                                                                                                    \
-        if ((rc = allow_lds(k_spa_b<SKV, LMV, YLV>, lds, "k_spa_b"))) return rc;                                            \
-        k_spa_b<SKV, LMV, YLV><<<ntile, 256, lds, st>>>(tok, q, k, v, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.h, d.w); \
+        if ((rc = allow_lds(k_spa_b<T, SKV, LMV, YLV>, lds, "k_spa_b"))) return rc;                                            \
+        k_spa_b<T, SKV, LMV, YLV><<<ntile, 256, lds, st>>>(tok, q, k, v, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.h, d.w); \
     } while (0)
         const bool tlm = tok_lane_major<T>(d);
         if (out_lm && !(skip && tlm)) return fail(LFT_ERR_ARG, "internal: lane-major output needs the skip variant and lane-major tokens");
@@ -527,7 +534,7 @@ int lft_pack_weights(const float* const* params, int nparams, void* packed, int 
         if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
     if ((rc = make_dims(1, A, h, w, s, prec, &d))) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    return prec == LFT_PREC_F32 ? pack_impl<float>(params, packed, d, prec, st) : pack_impl<bf16_t>(params, packed, d, prec, st);
+    return LFT_BY_PREC(prec, pack_impl<T>(params, packed, d, prec, st));
 }
 
 int lft_forward(const void* packed, const float* lr, float* out, void* workspace, int B, int A, int h, int w, int s, int prec, void* stream) {
@@ -535,8 +542,7 @@ int lft_forward(const void* packed, const float* lr, float* out, void* workspace
     if (!packed || !lr || !out || !workspace) return fail(LFT_ERR_ARG, "null pointer");
     if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    return prec == LFT_PREC_F32 ? forward_impl<float>(packed, lr, out, workspace, d, prec, st)
-                                : forward_impl<bf16_t>(packed, lr, out, workspace, d, prec, st);
+    return LFT_BY_PREC(prec, forward_impl<T>(packed, lr, out, workspace, d, prec, st));
 }
 
 int lft_forward_profiled(const void* packed, const float* lr, float* out, void* workspace, int B, int A, int h, int w, int s, int prec,
@@ -569,8 +575,7 @@ int lft_kernel_time(const char* kernel, const void* packed, void* workspace, int
     if (!kernel || !packed || !workspace || !ms_out || reps < 1) return fail(LFT_ERR_ARG, "bad argument");
     if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    return prec == LFT_PREC_F32 ? kernel_time_impl<float>(kernel, packed, workspace, d, prec, reps, st, ms_out)
-                                : kernel_time_impl<bf16_t>(kernel, packed, workspace, d, prec, reps, st, ms_out);
+    return LFT_BY_PREC(prec, kernel_time_impl<T>(kernel, packed, workspace, d, prec, reps, st, ms_out));
 }
 
 int lft_bicubic_fwd(const float* lr, float* out, int B, int A, int h, int w, int s, void* stream) {
@@ -591,11 +596,8 @@ int lft_init_features_fwd(const void* packed, const float* lr, void* act_out, vo
     const PackedLayout L = packed_layout(d, prec);
     const WorkLayout W = work_layout(d, prec);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (prec == LFT_PREC_F32)
-        return init_features<float>(packed, L, lr, at<float>(workspace, W.x0), at<float>(workspace, W.xa), at<float>(workspace, W.xb),
-                                    static_cast<float*>(act_out), d, st);
-    return init_features<bf16_t>(packed, L, lr, at<bf16_t>(workspace, W.x0), at<bf16_t>(workspace, W.xa), at<bf16_t>(workspace, W.xb),
-                                 static_cast<bf16_t*>(act_out), d, st);
+    return LFT_BY_PREC(prec, init_features<T>(packed, L, lr, at<T>(workspace, W.x0), at<T>(workspace, W.xa), at<T>(workspace, W.xb),
+                                              static_cast<T*>(act_out), d, st));
 }
 
 int lft_ang_block_fwd(const void* packed, int layer, const void* act_in, void* act_out, int B, int A, int h, int w, int s, int prec,
@@ -606,8 +608,7 @@ int lft_ang_block_fwd(const void* packed, int layer, const void* act_in, void* a
     if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
     const PackedLayout L = packed_layout(d, prec);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (prec == LFT_PREC_F32) return ang_block<float>(packed, L, layer, static_cast<const float*>(act_in), static_cast<float*>(act_out), d, st);
-    return ang_block<bf16_t>(packed, L, layer, static_cast<const bf16_t*>(act_in), static_cast<bf16_t*>(act_out), d, st);
+    return LFT_BY_PREC(prec, ang_block<T>(packed, L, layer, static_cast<const T*>(act_in), static_cast<T*>(act_out), d, st));
 }
 
 int lft_spa_block_fwd(const void* packed, int layer, const void* act_in, const void* skip, void* act_out, void* workspace, int B, int A,
@@ -619,11 +620,8 @@ int lft_spa_block_fwd(const void* packed, int layer, const void* act_in, const v
     const PackedLayout L = packed_layout(d, prec);
     const WorkLayout W = work_layout(d, prec);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (prec == LFT_PREC_F32)
-        return spa_block<float>(packed, L, layer, static_cast<const float*>(act_in), static_cast<const float*>(skip),
-                                static_cast<float*>(act_out), workspace, W, d, st);
-    return spa_block<bf16_t>(packed, L, layer, static_cast<const bf16_t*>(act_in), static_cast<const bf16_t*>(skip),
-                             static_cast<bf16_t*>(act_out), workspace, W, d, st);
+    return LFT_BY_PREC(prec, spa_block<T>(packed, L, layer, static_cast<const T*>(act_in), static_cast<const T*>(skip),
+                                          static_cast<T*>(act_out), workspace, W, d, st));
 }
 
 int lft_upsample_fwd(const void* packed, const void* act_in, const float* lr, float* out, void* workspace, int B, int A, int h, int w,
@@ -634,8 +632,7 @@ int lft_upsample_fwd(const void* packed, const void* act_in, const float* lr, fl
     const PackedLayout L = packed_layout(d, prec);
     const WorkLayout W = work_layout(d, prec);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (prec == LFT_PREC_F32) return upsample<float>(packed, L, static_cast<const float*>(act_in), lr, out, workspace, W, d, st);
-    return upsample<bf16_t>(packed, L, static_cast<const bf16_t*>(act_in), lr, out, workspace, W, d, st);
+    return LFT_BY_PREC(prec, upsample<T>(packed, L, static_cast<const T*>(act_in), lr, out, workspace, W, d, st));
 }
 
 // Debug aid (tools/stress_conv.py): one k_conv64 launch. which = 0..2 selects the weight stream, with_res the variant,
@@ -648,19 +645,16 @@ int lft_debug_conv64(const void* packed, int which, int with_res, const void* in
     const PackedLayout L = packed_layout(d, prec);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nimg = d.B * d.V, nwg = nimg * ((d.hw + 32 * kNwConv - 1) / (32 * kNwConv));
-    if (prec == LFT_PREC_F32) {
-        const size_t lds = lds_conv64<float>(d.w) + extra_lds;
-        if ((rc = allow_lds(k_conv64<float, false>, lds, "k_conv64"))) return rc;
-        if ((rc = allow_lds(k_conv64<float, true>, lds, "k_conv64"))) return rc;
-        if (with_res) k_conv64<float, true><<<nwg, 64 * kNwConv, lds, st>>>((const float*)in, (float*)out, (const float*)res, at<float>(packed, L.s_conv[which]), nimg, d.h, d.w);
-        else k_conv64<float, false><<<nwg, 64 * kNwConv, lds, st>>>((const float*)in, (float*)out, nullptr, at<float>(packed, L.s_conv[which]), nimg, d.h, d.w);
-    } else {
-        const size_t lds = lds_conv64<bf16_t>(d.w) + extra_lds;
-        if ((rc = allow_lds(k_conv64<bf16_t, false>, lds, "k_conv64"))) return rc;
-        if ((rc = allow_lds(k_conv64<bf16_t, true>, lds, "k_conv64"))) return rc;
-        if (with_res) k_conv64<bf16_t, true><<<nwg, 64 * kNwConv, lds, st>>>((const bf16_t*)in, (bf16_t*)out, (const bf16_t*)res, at<bf16_t>(packed, L.s_conv[which]), nimg, d.h, d.w);
-        else k_conv64<bf16_t, false><<<nwg, 64 * kNwConv, lds, st>>>((const bf16_t*)in, (bf16_t*)out, nullptr, at<bf16_t>(packed, L.s_conv[which]), nimg, d.h, d.w);
-    }
+    rc = LFT_BY_PREC(prec, [&]() -> int {
+        const size_t lds = lds_conv64<T>(d.w) + extra_lds;
+        int r;
+        if ((r = allow_lds(k_conv64<T, false>, lds, "k_conv64"))) return r;
+        if ((r = allow_lds(k_conv64<T, true>, lds, "k_conv64"))) return r;
+        if (with_res) k_conv64<T, true><<<nwg, 64 * kNwConv, lds, st>>>((const T*)in, (T*)out, (const T*)res, at<T>(packed, L.s_conv[which]), nimg, d.h, d.w);
+        else k_conv64<T, false><<<nwg, 64 * kNwConv, lds, st>>>((const T*)in, (T*)out, nullptr, at<T>(packed, L.s_conv[which]), nimg, d.h, d.w);
+        return 0;
+    }());
+    if (rc) return rc;
     LFT_LAUNCH_OK("k_conv64");
     return 0;
 }
@@ -715,6 +709,7 @@ int lft_mfma_selftest(const float* Am, const float* Bm, const float* W2, float* 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (prec == LFT_PREC_F32) k_selftest<float><<<1, 64, 0, st>>>(Am, Bm, W2, C, D);
     else if (prec == LFT_PREC_BF16) k_selftest<bf16_t><<<1, 64, 0, st>>>(Am, Bm, W2, C, D);
+    else if (prec == LFT_PREC_F16) k_selftest<f16_t><<<1, 64, 0, st>>>(Am, Bm, W2, C, D);
     else return fail(LFT_ERR_ARG, "bad prec %d", prec);
     LFT_LAUNCH_OK("k_selftest");
     return 0;

@@ -12,7 +12,9 @@
 //
 // Two operand precisions share all code:
 //   T = float : v_mfma_f32_32x32x2_f32 (exact fp32, the parity path)
-//   T = bf16  : v_mfma_f32_32x32x16_bf16 (fp32 accumulate, the throughput path)
+//   T = bf16  : v_mfma_f32_32x32x16_bf16 (fp32 accumulate, the throughput path; BASELINE configs[1] dtype)
+//   T = f16   : v_mfma_f32_32x32x16_f16, the same kernels and layouts with 11 significant bits instead of 8 -- the
+//               16-bit path that meets the 1e-3 parity tolerance (2e-4 observed); range 65504
 // One "k-step" always covers 16 k values; a fragment holds 8 of them per lane.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -24,6 +26,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// The two 16-bit operand types share every layout; H16<T> names their vector types.
+template <typename T> struct H16;
+template <> struct H16<bf16_t> { typedef bf16x4 v4; typedef bf16x8 v8; };
+template <> struct H16<f16_t> { typedef f16x4 v4; typedef f16x8 v8; };
 // Raw 16-byte moves (LDS staging, fragment reads) go through a may_alias type, so that type-based alias
 // analysis can never treat an LDS store and a differently-typed LDS load of the same bytes as independent.
 typedef unsigned int raw16 __attribute__((ext_vector_type(4), may_alias));
@@ -69,9 +78,8 @@ constexpr float LFT_LOG2E = 1.4426950408889634f;
 // Any labelling of the 16 k values works as long as A and B agree, which is what lets an
 // accumulator tile be re-used as an operand ("acc order", see acc_to_frag).
 // ------------------------------------------------------------------------------------------
-template <typename T> struct Frag;
+template <typename T> struct Frag { typename H16<T>::v8 v; };          // bf16 / f16
 template <> struct Frag<float> { f32x4 lo, hi; };
-template <> struct Frag<bf16_t> { bf16x8 v; };
 
 LFT_DEV void mma(const Frag<float>& a, const Frag<float>& b, f32x16& c) {
 #pragma unroll
@@ -79,15 +87,15 @@ LFT_DEV void mma(const Frag<float>& a, const Frag<float>& b, f32x16& c) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[j], b.hi[j], c, 0, 0, 0);
 }
-LFT_DEV void mma(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
-}
+LFT_DEV f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+LFT_DEV f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+template <typename T> LFT_DEV void mma(const Frag<T>& a, const Frag<T>& b, f32x16& c) { c = mfma16(a.v, b.v, c); }
 
 LFT_DEV Frag<float> frag_zero(float) { Frag<float> f; f.lo = f32x4{0, 0, 0, 0}; f.hi = f.lo; return f; }
-LFT_DEV Frag<bf16_t> frag_zero(bf16_t) {
-    Frag<bf16_t> f;
+template <typename T> LFT_DEV Frag<T> frag_zero(T) {
+    Frag<T> f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f.v[j] = (bf16_t)0.0f;
+    for (int j = 0; j < 8; ++j) f.v[j] = (T)0.0f;
     return f;
 }
 // keep elements j<4 (which==0) or j>=4 (which==1); the rest become zero
@@ -96,10 +104,10 @@ LFT_DEV Frag<float> frag_half(const Frag<float>& f, int which) {
     if (which == 0) g.hi = f32x4{0, 0, 0, 0}; else g.lo = f32x4{0, 0, 0, 0};
     return g;
 }
-LFT_DEV Frag<bf16_t> frag_half(const Frag<bf16_t>& f, int which) {
-    Frag<bf16_t> g = f;
+template <typename T> LFT_DEV Frag<T> frag_half(const Frag<T>& f, int which) {
+    Frag<T> g = f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) g.v[which == 0 ? j + 4 : j] = (bf16_t)0.0f;
+    for (int j = 0; j < 4; ++j) g.v[which == 0 ? j + 4 : j] = (T)0.0f;
     return g;
 }
 template <typename T> LFT_DEV Frag<T> frag_select(bool keep, const Frag<T>& f) { return keep ? f : frag_zero(T()); }
@@ -119,10 +127,10 @@ LFT_DEV Frag<float> acc_to_frag(const f32x16& a, int s, float) {
     for (int j = 0; j < 4; ++j) { f.lo[j] = a[8 * s + j]; f.hi[j] = a[8 * s + 4 + j]; }
     return f;
 }
-LFT_DEV Frag<bf16_t> acc_to_frag(const f32x16& a, int s, bf16_t) {
-    Frag<bf16_t> f;
+template <typename T> LFT_DEV Frag<T> acc_to_frag(const f32x16& a, int s, T) {
+    Frag<T> f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f.v[j] = (bf16_t)a[8 * s + j];
+    for (int j = 0; j < 8; ++j) f.v[j] = (T)a[8 * s + j];
     return f;
 }
 
@@ -131,9 +139,8 @@ LFT_DEV Frag<bf16_t> acc_to_frag(const f32x16& a, int s, bf16_t) {
 // 16 l .. 16 l + 15) -- exactly what one wave-wide global_load_lds_dwordx4 moves.  A bf16 fragment is one
 // piece (8 bf16 per lane); an fp32 fragment is two pieces (elements 0-3, then elements 4-7).
 // ------------------------------------------------------------------------------------------
-template <typename T> struct FragInfo;
+template <typename T> struct FragInfo { static constexpr int PIECES = 1; };      // bf16 / f16
 template <> struct FragInfo<float> { static constexpr int PIECES = 2; };
-template <> struct FragInfo<bf16_t> { static constexpr int PIECES = 1; };
 
 LFT_DEV raw16 load_raw16(const char* p) { return *reinterpret_cast<const raw16*>(p); }
 LFT_DEV void store_raw16(char* p, raw16 v) { *reinterpret_cast<raw16*>(p) = v; }
@@ -144,9 +151,9 @@ LFT_DEV Frag<float> frag_from_pieces(const char* base, int lane, float) {
     r.hi = __builtin_bit_cast(f32x4, load_raw16(base + 1024 + lane * 16));
     return r;
 }
-LFT_DEV Frag<bf16_t> frag_from_pieces(const char* base, int lane, bf16_t) {
-    Frag<bf16_t> r;
-    r.v = __builtin_bit_cast(bf16x8, load_raw16(base + lane * 16));
+template <typename T> LFT_DEV Frag<T> frag_from_pieces(const char* base, int lane, T) {
+    Frag<T> r;
+    r.v = __builtin_bit_cast(typename H16<T>::v8, load_raw16(base + lane * 16));
     return r;
 }
 template <typename T> LFT_DEV Frag<T> load_wfrag(const T* __restrict__ stream, int f, int lane) {
@@ -324,10 +331,10 @@ LFT_DEV Frag<float> load_row8(const float* __restrict__ p, bool ok, float) {
     if (!ok) r = frag_zero(0.0f);
     return r;
 }
-LFT_DEV Frag<bf16_t> load_row8(const bf16_t* __restrict__ p, bool ok, bf16_t) {
-    Frag<bf16_t> r;
-    r.v = *reinterpret_cast<const bf16x8*>(p);
-    if (!ok) r = frag_zero(bf16_t());
+template <typename T> LFT_DEV Frag<T> load_row8(const T* __restrict__ p, bool ok, T) {
+    Frag<T> r;
+    r.v = *reinterpret_cast<const typename H16<T>::v8*>(p);
+    if (!ok) r = frag_zero(T());
     return r;
 }
 
@@ -339,10 +346,10 @@ LFT_DEV Frag<float> lds_row8(const char* p, bool ok, float) {
     if (!ok) r = frag_zero(0.0f);
     return r;
 }
-LFT_DEV Frag<bf16_t> lds_row8(const char* p, bool ok, bf16_t) {
-    Frag<bf16_t> r;
-    r.v = __builtin_bit_cast(bf16x8, load_raw16(p));
-    if (!ok) r = frag_zero(bf16_t());
+template <typename T> LFT_DEV Frag<T> lds_row8(const char* p, bool ok, T) {
+    Frag<T> r;
+    r.v = __builtin_bit_cast(typename H16<T>::v8, load_raw16(p));
+    if (!ok) r = frag_zero(T());
     return r;
 }
 
@@ -351,16 +358,16 @@ LFT_DEV Frag<bf16_t> lds_row8(const char* p, bool ok, bf16_t) {
 // Lane (h, r) owns channels 32 nt + 8 g + 4 h + {0..3} (g = 0..3) of token r: 4-channel pieces.
 // ------------------------------------------------------------------------------------------
 LFT_DEV f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-LFT_DEV f32x4 load4(const bf16_t* p) {
-    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+template <typename T> LFT_DEV f32x4 load4(const T* p) {
+    typename H16<T>::v4 v = *reinterpret_cast<const typename H16<T>::v4*>(p);
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 LFT_DEV void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-LFT_DEV void store4(bf16_t* p, f32x4 v) {
-    bf16x4 o;
+template <typename T> LFT_DEV void store4(T* p, f32x4 v) {
+    typename H16<T>::v4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
-    *reinterpret_cast<bf16x4*>(p) = o;
+    for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
+    *reinterpret_cast<typename H16<T>::v4*>(p) = o;
 }
 
 // `row` must be readable for every lane (clamp the token index); lanes with !ok get zeros.
@@ -378,9 +385,8 @@ LFT_DEV void load_acc(const T* __restrict__ row, bool ok, int h, f32x16 (&a)[NT]
 }
 // Raw (unconverted) accumulator-layout pieces of a token row, for values that are loaded early but used late:
 // a bf16 row costs half the registers of its fp32 expansion while it waits.
-template <typename T> struct RawPiece;
+template <typename T> struct RawPiece { typedef typename H16<T>::v4 type; };      // bf16 / f16
 template <> struct RawPiece<float> { typedef f32x4 type; };
-template <> struct RawPiece<bf16_t> { typedef bf16x4 type; };
 template <int NT, typename T>
 LFT_DEV void load_acc_raw(const T* __restrict__ row, int h, typename RawPiece<T>::type (&p)[NT * 4]) {
 #pragma unroll
@@ -422,9 +428,9 @@ LFT_DEV int store_tile_lm(T* __restrict__ tile_base, int lane, const f32x16 (&a)
         for (int k = 0; k < 2; ++k) {
             T* dst = tile_base + ((size_t)(nt * 2 + k) * 64 + lane) * 8;
             if constexpr (sizeof(T) == 2) {
-                bf16x8 v;
+                typename H16<T>::v8 v;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (bf16_t)a[nt][8 * k + j];
+                for (int j = 0; j < 8; ++j) v[j] = (T)a[nt][8 * k + j];
                 store_raw16(reinterpret_cast<char*>(dst), __builtin_bit_cast(raw16, v));
             } else {
                 store_raw16(reinterpret_cast<char*>(dst), __builtin_bit_cast(raw16, f32x4{a[nt][8 * k], a[nt][8 * k + 1], a[nt][8 * k + 2], a[nt][8 * k + 3]}));
@@ -441,7 +447,7 @@ LFT_DEV void load_tile_lm(const T* __restrict__ tile_base, int lane, f32x16 (&a)
         for (int k = 0; k < 2; ++k) {
             const T* src = tile_base + ((size_t)(nt * 2 + k) * 64 + lane) * 8;
             if constexpr (sizeof(T) == 2) {
-                const bf16x8 v = __builtin_bit_cast(bf16x8, load_raw16(reinterpret_cast<const char*>(src)));
+                const auto v = __builtin_bit_cast(typename H16<T>::v8, load_raw16(reinterpret_cast<const char*>(src)));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) a[nt][8 * k + j] = (float)v[j];
             } else {
@@ -500,15 +506,15 @@ LFT_DEV void wave_lds_fence() {
     asm volatile("" ::: "memory");
 }
 LFT_DEV void lds_store4(char* p, f32x4 v, float) { store_raw16(p, __builtin_bit_cast(raw16, v)); }
-LFT_DEV void lds_store4(char* p, f32x4 v, bf16_t) {
-    bf16x4 o;
+template <typename T> LFT_DEV void lds_store4(char* p, f32x4 v, T) {
+    typename H16<T>::v4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+    for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
     *reinterpret_cast<unsigned long long __attribute__((may_alias))*>(p) = __builtin_bit_cast(unsigned long long, o);
 }
 LFT_DEV f32x4 lds_load4(const char* p, float) { return __builtin_bit_cast(f32x4, load_raw16(p)); }
-LFT_DEV f32x4 lds_load4(const char* p, bf16_t) {
-    const bf16x4 v = __builtin_bit_cast(bf16x4, *reinterpret_cast<const unsigned long long __attribute__((may_alias))*>(p));
+template <typename T> LFT_DEV f32x4 lds_load4(const char* p, T) {
+    const auto v = __builtin_bit_cast(typename H16<T>::v4, *reinterpret_cast<const unsigned long long __attribute__((may_alias))*>(p));
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 

@@ -177,7 +177,7 @@ LFT_DEV void conv3x3_tile(const char* lds_in, int tl, int y, int x, bool ok, int
         for (int ks = 0; ks < 4; ++ks) {
             Frag<T> b;
             if constexpr (sizeof(T) == 2) {
-                b.v = __builtin_bit_cast(bf16x8, load_raw16(row + (((2 * ks + hh) ^ sw) * 16)));
+                b.v = __builtin_bit_cast(typename H16<T>::v8, load_raw16(row + (((2 * ks + hh) ^ sw) * 16)));
             } else {
                 b.lo = __builtin_bit_cast(f32x4, load_raw16(row + (((4 * ks + 2 * hh) ^ sw) * 16)));
                 b.hi = __builtin_bit_cast(f32x4, load_raw16(row + (((4 * ks + 2 * hh + 1) ^ sw) * 16)));

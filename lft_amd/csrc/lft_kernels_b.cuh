@@ -240,7 +240,7 @@ static_assert(kSpaBChunk == 8 ? kSpaBSlotsB * kSpaBChunk * 1024 <= kSpaBScratchO
 // Two 16-byte query fragments of one head pair, loaded by inline asm so that hipcc neither counts them nor drains the
 // LDS-DMA in flight when they are used (it waits vmcnt(0) for ordinary loads while a global_load_lds is outstanding).
 // They complete with the counted wait at the top of their head pair's iteration (vmcnt retires in issue order).
-LFT_DEV void q_load_async(const bf16_t* p0, const bf16_t* p1, raw16& a, raw16& b) {
+template <typename T> LFT_DEV void q_load_async(const T* p0, const T* p1, raw16& a, raw16& b) {
     asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off" : "=&v"(a), "=&v"(b) : "v"(p0), "v"(p1) : "memory");
 }
 template <int N> LFT_DEV void wait_vm_q(raw16& a, raw16& b) {          // s_waitcnt vmcnt(N); names the asm-loaded registers so no use moves above it
@@ -248,11 +248,12 @@ template <int N> LFT_DEV void wait_vm_q(raw16& a, raw16& b) {          // s_wait
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool SKIP, bool TOKLM = false, bool YLM = false>   // TOKLM: k_spa1 wrote the tokens as lane-major 32-token tiles (w % 32 == 0: a tile = 32 columns of one image row); YLM: write the output so (consumer: k_up)
-__global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK, const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                  const bf16_t* __restrict__ Vv, const bf16_t* __restrict__ ws, const float* __restrict__ ln,
-                                                  const bf16_t* __restrict__ skip, bf16_t* __restrict__ Y, int h, int w) {
-    typedef bf16_t T;
+template <typename T, bool SKIP, bool TOKLM = false, bool YLM = false>   // TOKLM: k_spa1 wrote the tokens as lane-major 32-token tiles (w % 32 == 0: a tile = 32 columns of one image row); YLM: write the output so (consumer: k_up)
+__global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, const T* __restrict__ Q, const T* __restrict__ K,
+                                                  const T* __restrict__ Vv, const T* __restrict__ ws, const float* __restrict__ ln,
+                                                  const T* __restrict__ skip, T* __restrict__ Y, int h, int w) {
+    static_assert(sizeof(T) == 2, "k_spa_b is the 16-bit (bf16 / f16) part B; fp32 uses k_win_attn_lds + k_spa2");
+    typedef typename H16<T>::v8 V8;
     using Ring = WRingDeep<T, kSpaBChunk, 4, kSpaBSlots>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const bufA = smem;                                          // each buffer: K tile, then V tile, of one head pair
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
     // row-major Q: [token][128], head hd = channels 16 hd .. (natural order); lane-major: piece [k-step hd][32 hh + column] of
     // the tile of image row qy (acc order -- K / V come in the same order, so the dot products agree, and the channel order
     // of V^T's rows, i.e. of the attention output, is undone by packing Wo in natural k order: lft_api.hip)
-    const bf16_t* qptr = TOKLM ? Q + (img0 + (long long)min(qy, h - 1) * w + x0) * 128 + (32 * hh + bxl + (r & 7)) * 8
+    const T* qptr = TOKLM ? Q + (img0 + (long long)min(qy, h - 1) * w + x0) * 128 + (32 * hh + bxl + (r & 7)) * 8
                                : Q + qtok * 128 + 8 * hh;
     constexpr int kQHead = TOKLM ? 512 : 16, kQPair = 2 * kQHead;     // element stride from one head / head pair to the next
     // K / V halo tiles (8 x 36 tokens x 2 heads = 64 B per token, unpadded) come in by LDS-DMA: no staging registers, no
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
         wg_barrier_keep_vm();                                              // everybody's pieces of this head pair have landed
         LFT_STAMP(18 + 2 * hg);
         Frag<T> qf[2];
-        qf[0].v = __builtin_bit_cast(bf16x8, qa);
-        qf[1].v = __builtin_bit_cast(bf16x8, qb);
+        qf[0].v = __builtin_bit_cast(V8, qa);
+        qf[1].v = __builtin_bit_cast(V8, qb);
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl) {
 #if LFT_SPAB_TWOPASS
@@ -364,8 +365,8 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 Frag<T> kf;
-                kf.v = __builtin_bit_cast(bf16x8, load_raw16(buf + kofs[j] + hl * 32));
-                const f32x16 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, qf[hl].v, bias[j], 0, 0, 0);   // S^T[key, q] + mask bias
+                kf.v = __builtin_bit_cast(V8, load_raw16(buf + kofs[j] + hl * 32));
+                const f32x16 S = mfma16(kf.v, qf[hl].v, bias[j]);   // S^T[key, q] + mask bias
 #pragma unroll
                 for (int i = 0; i < 16; ++i) m = fmaxf(m, S[i]);
             }
@@ -376,9 +377,9 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 Frag<T> kf;
-                kf.v = __builtin_bit_cast(bf16x8, load_raw16(buf + kofs[j] + hl * 32));
+                kf.v = __builtin_bit_cast(V8, load_raw16(buf + kofs[j] + hl * 32));
                 asm volatile("" : "+v"(kf.v));                             // opaque: otherwise the two passes are merged and all three tiles stay live
-                f32x16 P = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, qf[hl].v, bias[j], 0, 0, 0);
+                f32x16 P = mfma16(kf.v, qf[hl].v, bias[j]);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { P[i] = fast_exp2(P[i] - m); sum += P[i]; }
 #pragma unroll
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
                     const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(buf + (c1 % 12 == 8 ? vb1 : vb0) + (c1 + 24 * (c1 / 12)) * 64));
                     Frag<T> vf;
-                    vf.v = __builtin_bit_cast(bf16x8, (short __attribute__((ext_vector_type(8)))){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
+                    vf.v = __builtin_bit_cast(V8, (short __attribute__((ext_vector_type(8)))){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
                     mma(vf, acc_to_frag(P, s2, T()), o);                      // O^T[d, q] += V^T P^T (rows of BOTH heads; only this head's 16 are kept)
                 }
                 __builtin_amdgcn_sched_barrier(0);                         // one score tile at a time (the scheduler would overlap all three again)
@@ -402,8 +403,8 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 Frag<T> kf;
-                kf.v = __builtin_bit_cast(bf16x8, load_raw16(buf + kofs[j] + hl * 32));
-                S[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, qf[hl].v, bias[j], 0, 0, 0);   // S^T[key, q] + mask bias
+                kf.v = __builtin_bit_cast(V8, load_raw16(buf + kofs[j] + hl * 32));
+                S[j] = mfma16(kf.v, qf[hl].v, bias[j]);   // S^T[key, q] + mask bias
 #pragma unroll
                 for (int i = 0; i < 16; ++i) m = fmaxf(m, S[j][i]);
             }
@@ -427,13 +428,13 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
                     const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(buf + (c1 % 12 == 8 ? vb1 : vb0) + (c1 + 24 * (c1 / 12)) * 64));
                     Frag<T> vf;
-                    vf.v = __builtin_bit_cast(bf16x8, (short __attribute__((ext_vector_type(8)))){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
+                    vf.v = __builtin_bit_cast(V8, (short __attribute__((ext_vector_type(8)))){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
                     mma(vf, acc_to_frag(S[j], s2, T()), o);                   // O^T[d, q] += V^T P^T (rows of BOTH heads; only this head's 16 are kept)
                 }
 #endif
             // rows 16 hl .. 16 hl + 15 (registers 8 hl .. 8 hl + 7) are this head's channels 32 hg + 16 hl + ..: k-step 2 hg + hl of out_proj
 #pragma unroll
-            for (int i = 0; i < 8; ++i) of[2 * hg + hl].v[i] = (bf16_t)(o[8 * hl + i] * inv);
+            for (int i = 0; i < 8; ++i) of[2 * hg + hl].v[i] = (T)(o[8 * hl + i] * inv);
             // keep the heads apart: left alone, the scheduler interleaves two heads (two sets of score tiles live) and
             // hoists the next head pair's work over this one's softmax -- 100+ spilled registers
             __builtin_amdgcn_sched_barrier(0);
@@ -457,10 +458,10 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
         // piece [k-step][32 hh + column] holds exactly registers 8k .. 8k+7 of this lane's accumulator tile (load_tile_lm),
         // so the token tile arrives with eight 16-byte loads per lane and no LDS transposition.
         const int ty_ = min(y0 + (r >> 3), h - 1);
-        const bf16_t* src = TOK + (img0 + (long long)ty_ * w + x0) * 128 + (32 * hh + bxl + (r & 7)) * 8;
+        const T* src = TOK + (img0 + (long long)ty_ * w + x0) * 128 + (32 * hh + bxl + (r & 7)) * 8;
 #pragma unroll
         for (int kidx = 0; kidx < 8; ++kidx) {
-            const bf16x8 v = __builtin_bit_cast(bf16x8, load_raw16(reinterpret_cast<const char*>(src + kidx * 512)));
+            const V8 v = __builtin_bit_cast(V8, load_raw16(reinterpret_cast<const char*>(src + kidx * 512)));
 #pragma unroll
             for (int j = 0; j < 8; ++j) t[kidx >> 1][8 * (kidx & 1) + j] = (float)v[j];
         }
@@ -504,12 +505,12 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const bf16_t* __restrict__ TOK
     }
     if constexpr (YLM) {                                              // the mirror image of the TOKLM load: four 16-byte stores per lane, no LDS
         if (qy < h) {
-            bf16_t* dst = Y + (img0 + (long long)qy * w + x0) * 64 + (32 * hh + bxl + (r & 7)) * 8;
+            T* dst = Y + (img0 + (long long)qy * w + x0) * 64 + (32 * hh + bxl + (r & 7)) * 8;
 #pragma unroll
             for (int kidx = 0; kidx < 4; ++kidx) {
-                bf16x8 v;
+                V8 v;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (bf16_t)y[kidx >> 1][8 * (kidx & 1) + j];
+                for (int j = 0; j < 8; ++j) v[j] = (T)y[kidx >> 1][8 * (kidx & 1) + j];
                 store_raw16(reinterpret_cast<char*>(dst + kidx * 512), __builtin_bit_cast(raw16, v));
             }
         }

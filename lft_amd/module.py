@@ -18,7 +18,8 @@ from . import _lib
 from .params import param_table
 
 _PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "float32": _lib.PREC_F32,
-         "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16}
+         "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16,
+         "fp16": _lib.PREC_F16, "f16": _lib.PREC_F16, "float16": _lib.PREC_F16}
 
 
 class _Node(nn.Module):
@@ -39,8 +40,9 @@ class get_model(nn.Module):
     """LFT network (reference model/LFT.py:8-83).  ``args`` needs ``channels`` (64), ``angRes``,
     ``scale_factor`` exactly as the reference reads them (LFT.py:11-14).
 
-    ``precision``: 'fp32' (exact-fp32 MFMA; parity path, default) or 'bf16' (bf16 MFMA operands,
-    fp32 accumulation).  May also be given as ``args.lft_precision``.
+    ``precision``: 'fp32' (exact-fp32 MFMA; 3e-7 of the reference, default), 'fp16' (IEEE-half MFMA operands and
+    inter-kernel tensors, fp32 accumulation; ~2e-4 of the reference at the speed of 'bf16') or 'bf16' (bf16 operands
+    and tensors; ~1.7e-3).  May also be given as ``args.lft_precision``.
     """
 
     def __init__(self, args, precision: Optional[str] = None, streams: Optional[int] = None):

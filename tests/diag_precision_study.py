@@ -23,6 +23,8 @@ def rnd(x, cls):
     m = POLICY.get(cls, "exact")
     if m == "exact":
         return x
+    if m == "fp16":
+        return x.to(torch.float16).float()
     hi = x.to(torch.bfloat16).float()
     if m == "bf16":
         return hi
@@ -134,6 +136,7 @@ def main():
             run(f"only {k} bf16", {k: "bf16"})
         for grp in ("store", "conv", "ang", "spa", "up"):
             run(f"all bf16 except {grp}.* exact", {k: v for k, v in allb.items() if not k.startswith(grp)})
+        run("everything fp16 (operands and storage)", {k: "fp16" for k in ALL})
         run("all bf16, weights x2 (hi+lo)", {k: ("x2" if k.endswith(".w") else "bf16") for k in ALL})
         run("all bf16, activations x2, storage x2", {k: ("bf16" if k.endswith(".w") else "x2") for k in ALL})
         run("all bf16, store.x exact", {k: v for k, v in allb.items() if k != "store.x"})

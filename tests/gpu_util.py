@@ -9,8 +9,8 @@ from lft_amd import _lib
 from lft_amd.params import deterministic_state, param_table
 
 DEV = "cuda:0"
-PRECS = {"fp32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}
-ACT_DTYPE = {"fp32": torch.float32, "bf16": torch.bfloat16}
+PRECS = {"fp32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "fp16": _lib.PREC_F16}
+ACT_DTYPE = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 
 
 def stream():

@@ -14,13 +14,13 @@ import gpu_util as G
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])
 def test_forward_is_bitwise_repeatable(prec):
     A, s, B, h, w = 5, 4, 4, 32, 32                      # BASELINE configs[1]: more workgroups than fit at once
     pk = G.Packed(deterministic_state(64, s, seed=1, flavor="stress"), A, h, w, s, prec, B)
     lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=0)).to(G.DEV)
     out = torch.empty(B, 1, A * h * s, A * w * s, device=G.DEV)
-    reps = 400 if prec == "bf16" else 60
+    reps = {"bf16": 400, "fp16": 200, "fp32": 60}[prec]
     outs = []
     for _ in range(reps):
         _lib.check(_lib.lib().lft_forward(pk.buf.data_ptr(), lr.data_ptr(), out.data_ptr(), pk.work.data_ptr(), *pk.dims(), G.stream()),

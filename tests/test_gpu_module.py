@@ -25,7 +25,7 @@ def make_net(A, s, wseed, flavor, precision):
 
 
 @pytest.mark.parametrize("name", GOLDEN)
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
 def test_forward_matches_reference_fixture(name, precision, golden_dir):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     A, s, B, h, w, wseed, iseed = [int(v) for v in g["meta"]]
@@ -37,10 +37,11 @@ def test_forward_matches_reference_fixture(name, precision, golden_dir):
     rel = float((out - ref).abs().max() / ref.abs().max())
     print(f"{name} [{precision}] rel max err {rel:.3e}  psnr(ours, reference) {O.psnr(out, ref):.2f} dB")
     assert out.shape == ref.shape
-    # north_star: 1e-3 relative -- met by the fp32 path (observed 3e-7).  The bf16 path rounds every MFMA operand and every
-    # inter-kernel tensor to 8 significant bits: 1.5e-3 .. 1.9e-3 observed, which does NOT meet 1e-3; its gate only pins that level.
-    assert rel <= (1e-3 if precision == "fp32" else BF16_END_TO_END)
-    assert O.psnr(out, ref) >= (100.0 if precision == "fp32" else 55.0)
+    # north_star: 1e-3 relative -- met by the fp32 path (observed 3e-7) and by the fp16 path (11 significant bits, ~2e-4).  The bf16
+    # path rounds every MFMA operand and every inter-kernel tensor to 8 significant bits: 1.5e-3 .. 1.9e-3 observed, which does NOT
+    # meet 1e-3; its gate only pins that level.
+    assert rel <= (BF16_END_TO_END if precision == "bf16" else 1e-3)
+    assert O.psnr(out, ref) >= {"fp32": 100.0, "fp16": 70.0, "bf16": 55.0}[precision]
 
 
 def test_batch_independence_cfg2():
@@ -62,7 +63,7 @@ def test_batch_independence_cfg2():
 def test_full_size_properties_cfg4_cfg5(A, s, B, h, w):
     """BASELINE configs[3] (64x64 LR views) and configs[4] (9x9 views) at full view size, where the CPU oracle is too slow
     to be the checker: size-independent properties instead -- batch independence and permutation equivariance
-    (bit-exact), the fp32 and bf16 paths agreeing to bf16 accuracy, and the network reducing to its bicubic skip when
+    (bit-exact), the bf16 and fp16 paths agreeing with the fp32 path to their accuracy (fp16: north_star's 1e-3), and the network reducing to its bicubic skip when
     the last convolution's weights are zero (the skip path is checked against the oracle at small sizes)."""
     net = make_net(A, s, 1, "default", "bf16")
     lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=4)).to("cuda:0")
@@ -79,6 +80,11 @@ def test_full_size_properties_cfg4_cfg5(A, s, B, h, w):
     rel = float((full[:1] - y32).abs().max() / y32.abs().max())
     print(f"A{A} {h}x{w}: bf16 vs fp32 path rel max {rel:.2e}")
     assert rel <= BF16_END_TO_END
+    with torch.no_grad():
+        y16 = make_net(A, s, 1, "default", "fp16")(lr[:1])
+    rel16 = float((y16 - y32).abs().max() / y32.abs().max())
+    print(f"A{A} {h}x{w}: fp16 vs fp32 path rel max {rel16:.2e}")
+    assert rel16 <= 1e-3                                   # north_star tolerance at BASELINE's full sizes
     with torch.no_grad():
         dict(ref32.named_parameters())["upsampling.3.weight"].zero_()
         skip_only = ref32(lr[:1])

@@ -4,8 +4,10 @@ against the fixtures captured from the real reference.
 
 Tolerances (BASELINE.json north_star: 1e-3 relative fp32):
   fp32 path : max|err| <= 1e-4 * max|ref| per stage (observed ~1e-6), <= 1e-3 * max|ref| required end to end
+  fp16 path : rms err <= 2e-3 * rms(ref) per stage; <= 1e-3 * max|ref| required end to end (observed ~2e-4: the bf16 kernels with
+              IEEE-half operands and tensors -- the fast path that meets north_star)
   bf16 path : rms err <= 1e-2 * rms(ref) per stage; end to end bounded at 2.5e-3 * max|ref| (observed 1.5e-3 .. 1.9e-3: bf16 operand
-              rounding, tests/diag_precision_study.py -- this path does NOT meet the 1e-3 of north_star; the fp32 path does)
+              rounding, tests/diag_precision_study.py -- this path does NOT meet the 1e-3 of north_star; the fp32 and fp16 paths do)
 """
 import os
 
@@ -23,6 +25,9 @@ pytestmark = pytest.mark.gpu
 
 FP32_STAGE_TOL = 1e-4
 BF16_STAGE_RMS = 1e-2
+FP16_STAGE_RMS = 2e-3
+END_TO_END = {"fp32": 1e-3, "fp16": 1e-3, "bf16": 2.5e-3}
+ALL_PRECS = ["fp32", "fp16", "bf16"]
 
 
 def check(got, ref, prec, what):
@@ -31,11 +36,11 @@ def check(got, ref, prec, what):
     if prec == "fp32":
         assert G.rel_max(got, ref) <= FP32_STAGE_TOL, msg
     else:
-        assert G.rel_rms(got, ref) <= BF16_STAGE_RMS, msg
+        assert G.rel_rms(got, ref) <= (FP16_STAGE_RMS if prec == "fp16" else BF16_STAGE_RMS), msg
     print(msg)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ALL_PRECS)
 def test_mfma_fragment_layout(prec):
     """C = A B and D = W2 C with asymmetric small-integer data (exact in bf16 and fp32)."""
     rng = np.random.default_rng(0)
@@ -53,7 +58,7 @@ def test_mfma_fragment_layout(prec):
     if prec == "fp32":      # |C| can exceed bf16's exact-integer range, so D is only exact in fp32
         assert torch.equal(D.cpu(), W2 @ Cref), "acc-order operand re-use wrong"
     else:
-        assert G.rel_max(D.cpu(), W2 @ Cref.bfloat16().float()) < 1e-6
+        assert G.rel_max(D.cpu(), W2 @ Cref.to(G.ACT_DTYPE[prec]).float()) < 1e-6
 
 
 @pytest.mark.parametrize("A,h,w,s", [(3, 7, 5, 2), (5, 8, 8, 4), (2, 4, 9, 4)])
@@ -80,11 +85,11 @@ def case(request):
     lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=0))
     taps = {}
     out = O.forward(sd, lr, A, s, taps)
-    packs = {p: G.Packed(sd_np, A, h, w, s, p, B) for p in ("fp32", "bf16")}
+    packs = {p: G.Packed(sd_np, A, h, w, s, p, B) for p in ALL_PRECS}
     return dict(A=A, s=s, B=B, h=h, w=w, sd=sd, lr=lr, taps=taps, out=out, packs=packs)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ALL_PRECS)
 def test_init_features(case, prec):
     pk = case["packs"][prec]
     lr = case["lr"].to(G.DEV)
@@ -95,7 +100,7 @@ def test_init_features(case, prec):
     check(G.from_act(act), case["taps"]["feat"], prec, "init_features")
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ALL_PRECS)
 @pytest.mark.parametrize("layer", [0, 3])
 def test_ang_block(case, prec, layer):
     pk = case["packs"][prec]
@@ -109,7 +114,7 @@ def test_ang_block(case, prec, layer):
     check(G.from_act(act), ref, prec, f"ang_block{layer}")
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ALL_PRECS)
 @pytest.mark.parametrize("layer,with_skip", [(0, False), (3, True)])
 def test_spa_block(case, prec, layer, with_skip):
     pk = case["packs"][prec]
@@ -125,7 +130,7 @@ def test_spa_block(case, prec, layer, with_skip):
     check(G.from_act(act), ref, prec, f"spa_block{layer}")
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ALL_PRECS)
 def test_upsample(case, prec):
     pk = case["packs"][prec]
     xin = G.to_act(case["taps"]["body"], prec)
@@ -140,7 +145,7 @@ def test_upsample(case, prec):
     check(out.cpu() - skip, ref, prec, "upsample(residual branch)")
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ALL_PRECS)
 def test_forward_vs_oracle(case, prec):
     pk = case["packs"][prec]
     lr = case["lr"].to(G.DEV)
@@ -152,6 +157,6 @@ def test_forward_vs_oracle(case, prec):
     got, ref = out.cpu(), case["out"]
     msg = f"forward [{prec}] " + G.err_report(got, ref) + f" psnr={O.psnr(got, ref):.2f}dB"
     print(msg)
-    assert G.rel_max(got, ref) <= (1e-3 if prec == "fp32" else 2.5e-3), msg
+    assert G.rel_max(got, ref) <= END_TO_END[prec], msg
     res_got, res_ref = got - case["taps"]["skip"], case["taps"]["res"]
-    assert G.rel_rms(res_got, res_ref) <= (1e-4 if prec == "fp32" else 2e-2), "residual branch: " + G.err_report(res_got, res_ref)
+    assert G.rel_rms(res_got, res_ref) <= {"fp32": 1e-4, "fp16": 4e-3, "bf16": 2e-2}[prec], "residual branch: " + G.err_report(res_got, res_ref)
