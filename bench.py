@@ -323,7 +323,7 @@ def main():
             out = step(lr)
         sync()
         dt = time.perf_counter() - t0
-    assert bool(torch.isfinite(out).all())
+    assert bool(torch.isfinite(out).all()) or os.environ.get("LFT_BENCH_EXPERIMENT")      # knock-out builds of tools/ab_build.py compute garbage
     note(f"rank {rank}: {args.steps} steps in {dt:.3f} s")
     dt = dp.barrier_max_seconds(dt, dev)          # MAX over ranks
 

@@ -234,6 +234,9 @@ struct WRing {
     // Every wave issues exactly PIECES_PER_WAVE DMA instructions per chunk (clamped to the last piece of the
     // stream when the chunk is short) so that the counted wait below is exact.
     LFT_MEM void issue(int c) {
+#ifdef LFT_EXP_NO_RING_DMA
+        if (c >= NBUF) return;                                         // experiment: the first fill only
+#endif
         if (c * CH >= nfrag) return;                                   // uniform: chunk does not exist
         const char* src = g + (size_t)c * CHUNK_BYTES;
         char* dst = lds + (c % NBUF) * CHUNK_BYTES;
@@ -289,6 +292,9 @@ struct WRingDeep {
         return lds + s * CHUNK_BYTES + (s >= split_slot ? split_gap : 0);
     }
     LFT_MEM void issue(int c) {                                         // every wave issues exactly PIECES_PER_WAVE pieces per existing chunk
+#ifdef LFT_EXP_NO_RING_DMA
+        if (c >= NBUF) return;
+#endif
         if (c * CH >= nfrag) return;
         const char* src = g + (size_t)c * CHUNK_BYTES;
         char* dst = slot(c);
@@ -431,7 +437,11 @@ LFT_DEV int store_tile_lm(T* __restrict__ tile_base, int lane, const f32x16 (&a)
                 typename H16<T>::v8 v;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (T)a[nt][8 * k + j];
+#ifndef LFT_EXP_NO_TILE_STORES
                 store_raw16(reinterpret_cast<char*>(dst), __builtin_bit_cast(raw16, v));
+#else
+                asm volatile("" :: "v"(v), "v"(dst));
+#endif
             } else {
                 store_raw16(reinterpret_cast<char*>(dst), __builtin_bit_cast(raw16, f32x4{a[nt][8 * k], a[nt][8 * k + 1], a[nt][8 * k + 2], a[nt][8 * k + 3]}));
                 store_raw16(reinterpret_cast<char*>(dst + 4), __builtin_bit_cast(raw16, f32x4{a[nt][8 * k + 4], a[nt][8 * k + 5], a[nt][8 * k + 6], a[nt][8 * k + 7]}));
@@ -669,7 +679,11 @@ LFT_DEV void store_tile_map(T* __restrict__ gbase, const RM& rm, int lane, const
 #pragma unroll
         for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
             const int idx = i * 64 + lane, row = pass * 16 + idx / IO::P16, pc = idx % IO::P16;
+#ifndef LFT_EXP_NO_TILE_STORES
             if (rm.ok(row)) store_raw16(reinterpret_cast<char*>(gbase) + rm.off(row) + pc * 16, v[i]);
+#else
+            asm volatile("" :: "v"(v[i]));
+#endif
         }
     }
 }
@@ -745,8 +759,34 @@ LFT_DEV void zero_acc(f32x16 (&a)[NT]) {
 // 2^x for softmax arguments (x <= 0): the bare v_exp_f32.  exp2f() wraps it in ldexp / compare / select range
 // handling (4 extra VALU instructions per call); results below 2^-126 flush to 0, which a softmax does not mind.
 LFT_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// ReLU, LeakyReLU(0.2) and a plain maximum on values hipcc cannot prove canonical (MFMA results, inline-asm outputs):
+// fmaxf() first quiets each such operand with a v_max_f32 x, x, x, and x > 0 ? x : 0.2 x is a compare, a multiply and a
+// select -- in kernels bound by vector-instruction issue.  v_med3_f32 against +inf needs no preparation: the median of
+// (x, 0, inf) is max(x, 0), of (x, 0.2 x, inf) the leaky form (any slope below 1; bit-identical to the select), of
+// (a, b, inf) max(a, b).  The +inf comes from an opaque s_mov: given the constant, hipcc folds the median back into a
+// canonicalising maximum.  (No inline-asm v_max on the values themselves: the hazard recogniser does not pad an asm
+// statement that reads an MFMA result, and such a read returns stale registers.)
+LFT_DEV float opaque_inf() { float v; asm("s_mov_b32 %0, 0x7f800000" : "=s"(v)); return v; }
+LFT_DEV float relu_fast(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, opaque_inf()); }
+LFT_DEV float lrelu02_fast(float x) { return __builtin_amdgcn_fmed3f(x, 0.2f * x, opaque_inf()); }
+LFT_DEV float max_fast(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, opaque_inf()); }
+// Exchange between the two 32-lane halves of a wave (token halves of the accumulator layout): gfx950's
+// v_permlane32_swap_b32 swaps lanes 32..63 of its first operand with lanes 0..31 of its second, so from two copies of v it
+// leaves (lower half's values in both halves, upper half's values in both halves) -- one VALU instruction instead of a
+// ds_bpermute_b32 round trip through the LDS crossbar and the lgkmcnt wait behind it.  From inline asm: the builtin of
+// this hipcc (ROCm 7.2) returns its first result twice.  s_nop 1: wait states between the VALU writes of the operands
+// and the swap, as the compiler inserts for the builtin.
+#ifndef LFT_XHALF_BPERMUTE
+LFT_DEV void xhalf_split(float v, float& lo, float& hi) {
+    lo = v; hi = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+}
+LFT_DEV float xhalf_sum(float v) { float lo, hi; xhalf_split(v, lo, hi); return lo + hi; }
+LFT_DEV float xhalf_max(float v) { float lo, hi; xhalf_split(v, lo, hi); return max_fast(lo, hi); }
+#else
 LFT_DEV float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 LFT_DEV float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+#endif
 
 // LayerNorm over the NT*32 channels of each token (biased variance, eps inside the sqrt, affine),
 // as nn.LayerNorm does (reference LFT.py:127,136,199,208).  In place.  gamma/beta may point to LDS (kernels

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv64(const T* __restrict__ in, T*
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nt][i] = acc[nt][i] > 0.0f ? acc[nt][i] : 0.2f * acc[nt][i];
+        for (int i = 0; i < 16; ++i) acc[nt][i] = lrelu02_fast(acc[nt][i]);
     if (RES) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[nt] += rr[nt];
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
         acc_frags<2, T>(x, xf);
 
         f32x16 q[2], k[2], v[2], o[2];
-        zero_acc<2>(q); zero_acc<2>(k); zero_acc<2>(v); zero_acc<2>(o);
+        zero_acc<2>(q); zero_acc<2>(k); zero_acc<2>(v);
         linear_lds<2, 4, T>(smem, 0, lane, nf, q);
         linear_lds<2, 4, T>(smem, 8, lane, nf, k);
 #pragma unroll
@@ -331,19 +331,31 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
 #pragma unroll
             for (int i = 1; i < NLIVE; ++i) m = fmaxf(m, S[i]);
             m = xhalf_max(m);
-            float sum = 0.0f;
+            // the kernel is bound by vector-instruction issue: subtract and sum as register pairs (v_pk_add_f32)
+            const f32x2 mm = {m, m};
+            f32x2 sum2 = {0.0f, 0.0f};
 #pragma unroll
-            for (int i = 0; i < NLIVE; ++i) { S[i] = fast_exp2(S[i] - m); sum += S[i]; }
+            for (int i = 0; i + 1 < NLIVE; i += 2) {
+                f32x2 d = f32x2{S[i], S[i + 1]} - mm;
+                d[0] = fast_exp2(d[0]); d[1] = fast_exp2(d[1]);
+                S[i] = d[0]; S[i + 1] = d[1];
+                sum2 += d;
+            }
+            float sum = sum2[0] + sum2[1];
+            if constexpr (NLIVE & 1) { S[NLIVE - 1] = fast_exp2(S[NLIVE - 1] - m); sum += S[NLIVE - 1]; }
 #pragma unroll
             for (int i = NLIVE; i < 16; ++i) S[i] = 0.0f;    // rows that are no view for any lane: probability 0 without computing it
             const float inv = sizeof(T) == 2 ? fast_rcp(xhalf_sum(sum)) : 1.0f / xhalf_sum(sum);
-            const bool mine = (r >> 3) == (hd & 3);          // this lane's channel belongs to head hd
+            // O^T of this head in a fresh accumulator: with V's 32 channels (4 heads) as the A operand every row of the product
+            // is computed, the head's own 8 rows = registers 4*(hd&3)..+3 are kept (normalised) -- cheaper than zeroing the other
+            // heads' channels of V per head (8 v_cndmask per head in a kernel bound by vector-instruction issue)
+            f32x16 oh;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-                mma(frag_select<T>(mine, acc_to_frag(v[nt], s2, T())), acc_to_frag(S, s2, T()), o[nt]);
-            // normalise afterwards: head hd owns output rows 8*(hd&3)..+7 = registers 4*(hd&3)..+3 of o[nt], written by no other head
+            for (int i = 0; i < 16; ++i) oh[i] = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[nt][4 * (hd & 3) + i] *= inv;
+            for (int s2 = 0; s2 < 2; ++s2) mma(acc_to_frag(v[nt], s2, T()), acc_to_frag(S, s2, T()), oh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[nt][4 * (hd & 3) + i] = oh[4 * (hd & 3) + i] * inv;
         }
 
         LFT_STAMP(4 + 5 * stamp_it);
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) hid[nt][i] = fmaxf(hid[nt][i], 0.0f);
+            for (int i = 0; i < 16; ++i) hid[nt][i] = relu_fast(hid[nt][i]);
         acc_frags<4, T>(hid, hf);
         linear_lds<2, 8, T>(smem, 48, lane, hf, x);
         LFT_STAMP(5 + 5 * stamp_it);
@@ -513,7 +525,7 @@ __global__ __launch_bounds__(64 * CT * NG) void k_ang_multi(const T* __restrict_
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) hid[nt][i] = fmaxf(hid[nt][i], 0.0f);
+            for (int i = 0; i < 16; ++i) hid[nt][i] = relu_fast(hid[nt][i]);
         acc_frags<4, T>(hid, hf);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa2(const T* __restri
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) hid[nt][i] = fmaxf(hid[nt][i], 0.0f);
+            for (int i = 0; i < 16; ++i) hid[nt][i] = relu_fast(hid[nt][i]);
         Frag<T> hf[4];
         acc_frags<2, T>(hid, hf);
         linear_ring<4, 4, T>(ring, hf, t);
@@ -213,9 +213,6 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa2(const T* __restri
 // ring + K/V halo tiles stay below 80 KiB and two workgroups share a CU.  TOK / skip / Y are row-major [token][channel];
 // a wave's 8 x 4 block is four runs of 8 consecutive tokens (BlkRows).
 // ------------------------------------------------------------------------------------------
-#ifndef LFT_SPAB_TWOPASS
-#define LFT_SPAB_TWOPASS 0
-#endif
 #ifndef LFT_SPAB_CHUNK
 #define LFT_SPAB_CHUNK 8
 #endif
@@ -356,48 +353,6 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
         qf[1].v = __builtin_bit_cast(V8, qb);
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl) {
-#if LFT_SPAB_TWOPASS
-            // Two passes over the three score tiles, the second one RECOMPUTING them (3 more MFMAs on an idle matrix pipe):
-            // only one 32 x 32 score tile is live at a time instead of three -- 32 registers that decide between a clean
-            // allocation and spills inside this loop (a spill reload drains the LDS-DMA in flight).
-            f32x16 o;
-            float m = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                Frag<T> kf;
-                kf.v = __builtin_bit_cast(V8, load_raw16(buf + kofs[j] + hl * 32));
-                const f32x16 S = mfma16(kf.v, qf[hl].v, bias[j]);   // S^T[key, q] + mask bias
-#pragma unroll
-                for (int i = 0; i < 16; ++i) m = fmaxf(m, S[i]);
-            }
-            m = fmaxf(xhalf_max(m), -1.0e30f);                               // empty window: keep exp2(-inf - m) = 0, not NaN
-            float sum = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[i] = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                Frag<T> kf;
-                kf.v = __builtin_bit_cast(V8, load_raw16(buf + kofs[j] + hl * 32));
-                asm volatile("" : "+v"(kf.v));                             // opaque: otherwise the two passes are merged and all three tiles stay live
-                f32x16 P = mfma16(kf.v, qf[hl].v, bias[j]);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { P[i] = fast_exp2(P[i] - m); sum += P[i]; }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int c0 = 32 * j + 16 * s2, c1 = c0 + 8;
-                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(buf + (c0 % 12 == 8 ? vb1 : vb0) + (c0 + 24 * (c0 / 12)) * 64));
-                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(buf + (c1 % 12 == 8 ? vb1 : vb0) + (c1 + 24 * (c1 / 12)) * 64));
-                    Frag<T> vf;
-                    vf.v = __builtin_bit_cast(V8, (short __attribute__((ext_vector_type(8)))){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
-                    mma(vf, acc_to_frag(P, s2, T()), o);                      // O^T[d, q] += V^T P^T (rows of BOTH heads; only this head's 16 are kept)
-                }
-                __builtin_amdgcn_sched_barrier(0);                         // one score tile at a time (the scheduler would overlap all three again)
-            }
-            sum = xhalf_sum(sum);
-            const float inv = sum > 0.0f ? fast_rcp(sum) : 0.0f;                // empty window (h < w quirk): 0, as the pinned reference
-#else
             f32x16 S[3], o;
             float m = -INFINITY;
 #pragma unroll
@@ -409,12 +364,19 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
                 for (int i = 0; i < 16; ++i) m = fmaxf(m, S[j][i]);
             }
             m = fmaxf(xhalf_max(m), -1.0e30f);                               // empty window: keep exp2(-inf - m) = 0, not NaN
-            float sum = 0.0f;
+            // this phase is bound by vector-instruction issue: subtract and sum as register pairs (v_pk_add_f32)
+            const f32x2 mm = {m, m};
+            f32x2 sum2 = {0.0f, 0.0f};
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { S[j][i] = fast_exp2(S[j][i] - m); sum += S[j][i]; }
-            sum = xhalf_sum(sum);
+                for (int i = 0; i < 16; i += 2) {
+                    f32x2 d = f32x2{S[j][i], S[j][i + 1]} - mm;
+                    d[0] = fast_exp2(d[0]); d[1] = fast_exp2(d[1]);
+                    S[j][i] = d[0]; S[j][i + 1] = d[1];
+                    sum2 += d;
+                }
+            const float sum = xhalf_sum(sum2[0] + sum2[1]);
             const float inv = sum > 0.0f ? fast_rcp(sum) : 0.0f;                // empty window (h < w quirk): 0, as the pinned reference
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[i] = 0.0f;
@@ -431,7 +393,6 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
                     vf.v = __builtin_bit_cast(V8, (short __attribute__((ext_vector_type(8)))){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
                     mma(vf, acc_to_frag(S[j], s2, T()), o);                   // O^T[d, q] += V^T P^T (rows of BOTH heads; only this head's 16 are kept)
                 }
-#endif
             // rows 16 hl .. 16 hl + 15 (registers 8 hl .. 8 hl + 7) are this head's channels 32 hg + 16 hl + ..: k-step 2 hg + hl of out_proj
 #pragma unroll
             for (int i = 0; i < 8; ++i) of[2 * hg + hl].v[i] = (T)(o[8 * hl + i] * inv);
@@ -485,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) hid[nt][i] = fmaxf(hid[nt][i], 0.0f);
+            for (int i = 0; i < 16; ++i) hid[nt][i] = relu_fast(hid[nt][i]);
         Frag<T> hf[4];
         acc_frags<2, T>(hid, hf);
         linear_ring<4, 4, T>(ring, hf, t);
@@ -554,7 +515,7 @@ __global__ __launch_bounds__(64 * NW) void k_up(const T* __restrict__ X, const T
         zero_acc<1>(u);
         linear_ring<1, 4, T>(ring, xf, u);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) u[0][i] = u[0][i] > 0.0f ? u[0][i] : 0.2f * u[0][i];
+        for (int i = 0; i < 16; ++i) u[0][i] = lrelu02_fast(u[0][i]);
         Frag<T> uf[2];
         acc_frags<1, T>(u, uf);
         linear_ring<GT, 2, T>(ring, uf, g);
