@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LFT_ABI_VERSION 2
+#define LFT_ABI_VERSION 3
 #define LFT_PREC_F32 0
 #define LFT_PREC_BF16 1
 #define LFT_PREC_F16 2
@@ -126,6 +126,23 @@ int lft_train_forward(const float* const* params, int nparams, const float* lr, 
                       int B, int A, int h, int w, int s, int math, void* stream);
 int lft_train_backward(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
                        int B, int A, int h, int w, int s, int math, void* stream, void* side_stream);
+/* The same pass for data-parallel training (the reference's DP recipe, SURVEY.md section 8e: gradients summed over ranks):
+ * the flat gradient buffer is finished in LFT_GRAD_BUCKETS contiguous ranges, in this order --
+ *   bucket 0: altblock.2, altblock.3, upsampling   (after the backward of layer 2)
+ *   bucket 1: altblock.0, altblock.1               (after layer 0)
+ *   bucket 2: conv_init0, conv_init                (end of the pass)
+ * -- and on_bucket(user, bucket, first_float, n_floats) is called ON THE HOST, from inside this call, right after the last
+ * kernel writing that range has been enqueued on `stream` (the weight-gradient side stream joined).  The caller orders a
+ * communication stream after `stream` there and starts the bucket's all-reduce, which then runs beside the kernels of the
+ * remaining buckets; or, while capturing, ends one graph and begins the next (lft_amd/train.py does the latter).  Nothing
+ * enqueued after the callback touches the bucket's range.  lft_train_backward is this function without notifications;
+ * both produce identical bits.  lft_train_grad_bucket gives the ranges (floats) without running anything. */
+#define LFT_GRAD_BUCKETS 3
+typedef void (*lft_bucket_fn)(void* user, int bucket, size_t first_float, size_t n_floats);
+int lft_train_backward_buckets(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
+                               int B, int A, int h, int w, int s, int math, void* stream, void* side_stream,
+                               lft_bucket_fn on_bucket, void* user);
+int lft_train_grad_bucket(int s, int bucket, size_t* first_float, size_t* n_floats);
 /* get_loss (reference LFT.py:269-277, torch.nn.L1Loss): *loss = mean |sr - hr|; if dsr != NULL also
  * dsr = gscale * sign(sr - hr) (gscale = 1/n for d loss / d sr).  scratch1024: 1024 floats of device scratch. */
 int lft_l1_loss(const float* sr, const float* hr, long long n, float* dsr, float gscale, float* loss, float* scratch1024, void* stream);

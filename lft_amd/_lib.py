@@ -72,6 +72,9 @@ _SIGS = {
     "lft_train_tape_offset": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "lft_train_forward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lft_train_backward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "lft_train_backward_buckets": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                           c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lft_train_grad_bucket": (c_int, [c_int, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     "lft_l1_loss": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "lft_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_void_p]),
     "lft_view_metrics_scratch_bytes": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
@@ -80,6 +83,8 @@ _SIGS = {
     "lft_mfma_selftest": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
+GRAD_BUCKETS = 3
+BUCKET_FN = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_size_t, c_size_t)      # lft_bucket_fn of include/lft_hip.h
 
 
 def lib() -> ctypes.CDLL:

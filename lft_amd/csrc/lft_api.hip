@@ -800,6 +800,26 @@ int lft_train_backward(const float* const* params, int nparams, const float* lr,
     if (side_stream == stream) side_stream = nullptr;
     return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, math, static_cast<hipStream_t>(stream), static_cast<hipStream_t>(side_stream));
 }
+int lft_train_backward_buckets(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
+                               int B, int A, int h, int w, int s, int math, void* stream, void* side_stream,
+                               lft_bucket_fn on_bucket, void* user) {
+    Dims d; int rc;
+    if (!params || !lr || !tape || !dout || !grads || !on_bucket) return fail(LFT_ERR_ARG, "null pointer");
+    if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
+    for (int i = 0; i < nparams; ++i) if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
+    if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
+    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32 or LFT_MATH_BF16X3, got %d", math);
+    if (side_stream == stream) side_stream = nullptr;
+    return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, math, static_cast<hipStream_t>(stream),
+                          static_cast<hipStream_t>(side_stream), on_bucket, user);
+}
+int lft_train_grad_bucket(int s, int bucket, size_t* first_float, size_t* n_floats) {
+    if (!first_float || !n_floats) return fail(LFT_ERR_ARG, "null pointer");
+    if (s != 2 && s != 4) return fail(LFT_ERR_SHAPE, "scale factor must be 2 or 4, got %d", s);
+    if (bucket < 0 || bucket >= LFT_GRAD_BUCKETS) return fail(LFT_ERR_ARG, "bucket %d out of range (0..%d)", bucket, LFT_GRAD_BUCKETS - 1);
+    grad_bucket_range(s, bucket, first_float, n_floats);
+    return 0;
+}
 int lft_l1_loss(const float* sr, const float* hr, long long n, float* dsr, float gscale, float* loss, float* scratch1024, void* stream) {
     if (!sr || !hr || !loss || !scratch1024 || n < 1) return fail(LFT_ERR_ARG, "bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -428,8 +428,21 @@ int train_forward(const float* const* P, const float* lr, float* out, float* tap
 }
 
 // ---------------------------------------------------------------------------- backward
+// Gradient buckets, in the order the backward pass finishes them: contiguous ranges of the flat gradient buffer
+// (state_dict order: conv_init0, conv_init, altblock.0 .. 3, upsampling), so a data-parallel job can all-reduce bucket b
+// while the kernels of bucket b+1 run.
+static_assert(LFT_GRAD_BUCKETS == 3, "bucket ranges below");
+void grad_bucket_range(int s, int bucket, size_t* first, size_t* count) {
+    const ParamInfo pi = param_info(s);
+    const size_t cut1 = pi.off[4 + 18 * 2], cut0 = pi.off[4];        // altblock.2 / altblock.0 start
+    if (bucket == 0) { *first = cut1; *count = pi.total - cut1; }        // altblock.2, altblock.3, upsampling: ready after layer 2
+    else if (bucket == 1) { *first = cut0; *count = cut1 - cut0; }      // altblock.0, altblock.1
+    else { *first = 0; *count = cut0; }                                  // conv_init0, conv_init
+}
+typedef void (*BucketFn)(void* user, int bucket, size_t first_float, size_t n_floats);
+
 int train_backward(const float* const* P, const float* lr, float* tape, const float* dout, float* G, const Dims& d, int math,
-                   hipStream_t st, hipStream_t side) {
+                   hipStream_t st, hipStream_t side, BucketFn on_bucket = nullptr, void* user = nullptr) {
     const TrainLayout T = train_layout(d);
     const WViews WV = build_views(nullptr, d.s, nullptr);            // packed by this step's lft_train_forward
     RedTab red{};                                                    // every partial-sum producer registers a segment here
@@ -442,13 +455,48 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
     auto g = [&](int idx) { return G + pi.off[idx]; };
     size_t soff = 0;
     auto nb = [&](int width) { float* p = c.F(T.bwd) + soff; soff += (size_t)N * width; return p; };   // fresh [N][width] gradient buffer
+    // End of a gradient bucket: the weight-gradient stream joins, the partial sums registered since the last bucket are
+    // reduced (one table-driven launch), then the caller is told -- everything enqueued before the callback belongs to the
+    // bucket, nothing after it touches the bucket's range of G.
+    int red_done = 0;
+    float* dM = nullptr;
+    auto end_bucket = [&](int bucket) -> int {
+        if (side) {
+            hipEvent_t ev = next_event();
+            if (!ev) return fail(LFT_ERR_ARG, "hipEventCreate failed");
+            LFT_HIP_OK(hipEventRecord(ev, side));
+            LFT_HIP_OK(hipStreamWaitEvent(st, ev, 0));
+        }
+        RedTab sub{};
+        for (int i = red_done; i < red.nseg; ++i) {
+            sub.s[sub.nseg] = red.s[i];
+            sub.s[sub.nseg].blk0 = sub.nblk;
+            sub.nblk += (red.s[i].n + 63) / 64;
+            ++sub.nseg;
+        }
+        red_done = red.nseg;
+        if (sub.nseg) {
+            k_reduce_all<<<sub.nblk, 256, 0, st>>>(sub, c.F(T.part), G);
+            LFT_LAUNCH_OK("k_reduce_all");
+        }
+        if (bucket == 0) {                                           // upsampling.3.weight: the reduced dM folded onto the 3x3 taps
+            k_upm_fold<<<3, 256, 0, st>>>(dM, g(P_UP3), d.s);
+            LFT_LAUNCH_OK("k_upm_fold");
+        }
+        if (on_bucket) {
+            size_t first, count;
+            grad_bucket_range(d.s, bucket, &first, &count);
+            on_bucket(user, bucket, first, count);
+        }
+        return 0;
+    };
     // ---- up-sampler tail (the transpose of its forward: gather, GEMM with the overlap-add matrix) ----
     float* gu = c.F(T.gu);
     const int gt = (d.gp + 31) / 32;
     float* dG = nb(32 * gt);
     k_up_gather_bwd<<<blocks_for(N * 32 * gt, 256), 256, 0, st>>>(dout, dG, d.B, d.A, d.h, d.w, d.s, 32 * gt);
     LFT_LAUNCH_OK("k_up_gather_bwd");
-    float* dM = c.F(T.bwd) + soff;                                   // [32 gt][64 s^2], folded onto upsampling.3.weight at the end
+    dM = c.F(T.bwd) + soff;                                          // [32 gt][64 s^2], folded onto upsampling.3.weight at the end of bucket 0
     soff += (size_t)32 * gt * 64 * ss;
     TRY(wgrad(c, dG, 32 * gt, c.F(T.act), 64 * ss, 1, dM, 0, N));
     TRY(run_lin(c, VW_UPM_B, 0, 0, dG, 32 * gt, 0, 0, nullptr, 0, gu, 64 * ss, N, c.F(T.act), 2));   // dU = (M^T dG) * lrelu'(U)
@@ -529,6 +577,8 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
             TRY(ln_bwd(c, 64, xin, c.F(T.pe_ang), 1, P[pidx(l, A_N1W)], dn, dxa, dxo, g(pidx(l, A_N1W)), g(pidx(l, A_N1B)), N));   // ... + d LN(x + PE)
             dy = dxo;
         }
+        if (l == 2) TRY(end_bucket(0));
+        if (l == 0) TRY(end_bucket(1));
     }
     // ---- initial feature extractor ----
     float* dfeat = nb(64);
@@ -554,16 +604,7 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
         LFT_LAUNCH_OK("k_conv0_wgrad");
         TRY(red_push(c, poff, kTailWaves, 576, 576, g(P_CONV0), 0));
     }
-    if (side) {                                                      // the weight-gradient stream joins before the reduction
-        hipEvent_t ev = next_event();
-        if (!ev) return fail(LFT_ERR_ARG, "hipEventCreate failed");
-        LFT_HIP_OK(hipEventRecord(ev, side));
-        LFT_HIP_OK(hipStreamWaitEvent(st, ev, 0));
-    }
-    k_reduce_all<<<red.nblk, 256, 0, st>>>(red, c.F(T.part), G);      // every gradient's partial sums, one launch
-    LFT_LAUNCH_OK("k_reduce_all");
-    k_upm_fold<<<3, 256, 0, st>>>(dM, g(P_UP3), d.s);
-    LFT_LAUNCH_OK("k_upm_fold");
+    TRY(end_bucket(2));
 #undef TRY
     return 0;
 }

@@ -6,8 +6,10 @@ ROCm, "gloo" in the CPU tests) is only used for the barrier / max-over-ranks of 
 for gathering results where a caller wants them on one rank.
 
 Training (BASELINE config 3) has exactly one exchange per step: the sum of the flat gradient buffer
-(1.11 M floats, 4.5 MB) over the ranks -- ``sum_gradients_``; the division by the world size is folded into
-the Adam kernel (lft_amd/train.py:TrainStep).
+(1.11 M floats, 4.5 MB) over the ranks; the division by the world size is folded into the Adam kernel
+(lft_amd/train.py:TrainStep).  The buffer is summed in the three contiguous buckets in which the backward pass finishes
+it (``sum_gradients_start_`` / ``sum_gradients_finish``): the all-reduce of a bucket runs on the process group's own
+stream beside the backward kernels of the next one.  ``sum_gradients_`` is the one-call form.
 """
 from __future__ import annotations
 
@@ -98,3 +100,40 @@ def sum_gradients_(flat: torch.Tensor, group=None, force: bool = False) -> float
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
+
+
+def dp_active(group=None, force: bool = False) -> bool:
+    """True when gradients have to be exchanged: a process group of more than one rank (or a forced one-rank rehearsal)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or force or _force()
+
+
+def grad_scale(group=None) -> float:
+    """1 / world: turns the SUM of per-shard mean-loss gradients into the global-batch gradient (equal shards)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    return 1.0 / dist.get_world_size(group)
+
+
+def sum_gradients_start_(bucket: torch.Tensor, group=None):
+    """Start the in-place SUM all-reduce of one contiguous gradient bucket; returns a handle for sum_gradients_finish.
+    NCCL (= RCCL) backend: asynchronous -- the collective is ordered after the work already enqueued on the current
+    stream and runs on the process group's stream, so kernels enqueued afterwards overlap it.  gloo with a device tensor
+    (CPU rehearsals, several ranks sharing one GPU): through the host, finished on return."""
+    import torch.distributed as dist
+    if bucket.is_cuda and dist.get_backend(group) == "gloo":
+        host = bucket.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        bucket.copy_(host)
+        return None
+    return dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def sum_gradients_finish(handles) -> None:
+    """Order the current stream after the collectives started by sum_gradients_start_ (no host synchronisation with NCCL)."""
+    for h in handles:
+        if h is not None:
+            h.wait()

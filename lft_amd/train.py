@@ -97,6 +97,41 @@ def train_backward(ps, lr, tape, dout, A, s, grads=None, math="fp32", overlap=Tr
     return grads
 
 
+def grad_bucket(s: int, bucket: int):
+    """(first_float, n_floats) of gradient bucket `bucket` in the flat buffer (include/lft_hip.h: lft_train_grad_bucket)."""
+    first, count = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _lib.check(_lib.lib().lft_train_grad_bucket(s, bucket, ctypes.byref(first), ctypes.byref(count)), "lft_train_grad_bucket")
+    return first.value, count.value
+
+
+def train_backward_buckets(ps, lr, tape, dout, A, s, grads, on_bucket, math="fp32", overlap=True):
+    """lft_train_backward_buckets: the backward pass, calling on_bucket(bucket, first_float, n_floats) on the host each
+    time a contiguous range of the flat gradient buffer is final (its last kernel enqueued on the current stream).
+    An exception raised by on_bucket is re-raised here after the call returns."""
+    B, _, H, W = lr.shape
+    h, w = H // A, W // A
+    dev = lr.device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    err = []
+
+    def trampoline(_user, bucket, first, count):
+        if err:
+            return
+        try:
+            on_bucket(int(bucket), int(first), int(count))
+        except BaseException as e:          # noqa: BLE001 -- must not propagate through the C frame
+            err.append(e)
+
+    cb = _lib.BUCKET_FN(trampoline)
+    rc = _lib.lib().lft_train_backward_buckets(_ptr_array(ps), len(ps), lr.data_ptr(), tape.data_ptr(), dout.data_ptr(), grads.data_ptr(),
+                                               B, A, h, w, s, MATH[math], stream, side_stream(dev).cuda_stream if overlap else None,
+                                               ctypes.cast(cb, ctypes.c_void_p), None)
+    if err:
+        raise err[0]
+    _lib.check(rc, "lft_train_backward_buckets")
+    return grads
+
+
 class LFTFunction(torch.autograd.Function):
     """autograd node of the whole network: forward saves the tape, backward returns the 78 parameter gradients."""
 
@@ -127,8 +162,10 @@ class TrainStep:
 
     net: lft_amd.module.get_model on a HIP device.  After construction the module's parameters are views into
     ``self.flat_params`` (state_dict / checkpoints keep working).  ``step(lr, hr)`` returns the loss tensor (device
-    scalar, local shard).  With torch.distributed initialised, gradients are summed with ONE all-reduce of the flat
-    buffer and averaged inside the Adam kernel (L1Loss is a mean over the local shard, shards are equal: SURVEY 8e).
+    scalar, local shard).  With torch.distributed initialised, the flat gradient buffer is summed over the ranks in the three
+    contiguous buckets in which the backward pass finishes it -- each bucket's all-reduce starts as soon as its last
+    kernel is enqueued and runs beside the rest of the backward pass -- and averaged inside the Adam kernel (L1Loss is a
+    mean over the local shard, shards are equal: SURVEY 8e).
     """
 
     def __init__(self, net, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, math: Optional[str] = None,
@@ -169,7 +206,7 @@ class TrainStep:
         self._tape = None
         self._scratch = torch.empty(1024 + 1, dtype=torch.float32, device=dev)
 
-    def _fwd_loss_bwd(self, lr_in, hr, tape, dout, loss):
+    def _fwd_loss_bwd(self, lr_in, hr, tape, dout, loss, on_bucket=None):
         L = _lib.lib()
         dev = lr_in.device
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -177,11 +214,17 @@ class TrainStep:
         n = out.numel()
         _lib.check(L.lft_l1_loss(out.data_ptr(), hr.data_ptr(), n, dout.data_ptr(), 1.0 / n, loss.data_ptr(),
                                  self._scratch.data_ptr(), stream), "lft_l1_loss")
-        train_backward(self.params, lr_in, tape, dout, self.A, self.s, grads=self.flat_grads, math=self.math)
+        if on_bucket is None:
+            train_backward(self.params, lr_in, tape, dout, self.A, self.s, grads=self.flat_grads, math=self.math)
+        else:
+            train_backward_buckets(self.params, lr_in, tape, dout, self.A, self.s, self.flat_grads, on_bucket, math=self.math)
         return out
 
-    def _graph_for(self, lr_in, hr):
-        key = (tuple(lr_in.shape), str(lr_in.device))
+    def _graph_for(self, lr_in, hr, bucketed=False):
+        """Captured forward + loss + backward for this batch shape.  bucketed (data-parallel): one graph per gradient
+        bucket -- the capture is ended and the next one begun at every bucket boundary the backward pass reports, so that
+        step() can start a bucket's all-reduce between two replays."""
+        key = (tuple(lr_in.shape), str(lr_in.device), bool(bucketed))
         g = self._graphs.get(key)
         if g is None:
             dev = lr_in.device
@@ -195,32 +238,68 @@ class TrainStep:
                 self._fwd_loss_bwd(g["lr"], g["hr"], g["tape"], g["dout"], self._scratch[1024:1025])
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
-            g["graph"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g["graph"]):
-                g["out"] = self._fwd_loss_bwd(g["lr"], g["hr"], g["tape"], g["dout"], self._scratch[1024:1025])
+            if not bucketed:
+                g["graphs"] = [torch.cuda.CUDAGraph()]
+                with torch.cuda.graph(g["graphs"][0]):
+                    g["out"] = self._fwd_loss_bwd(g["lr"], g["hr"], g["tape"], g["dout"], self._scratch[1024:1025])
+            else:
+                graphs = [torch.cuda.CUDAGraph() for _ in range(_lib.GRAD_BUCKETS)]
+                state = {"open": 0}
+
+                def boundary(bucket, first, count):            # host callback between two kernels of the backward pass
+                    assert bucket == state["open"], (bucket, state["open"])
+                    graphs[bucket].capture_end()
+                    state["open"] = bucket + 1
+                    if bucket + 1 < len(graphs):
+                        graphs[bucket + 1].capture_begin(pool=graphs[0].pool())
+
+                with torch.cuda.stream(side):
+                    graphs[0].capture_begin()
+                    try:
+                        g["out"] = self._fwd_loss_bwd(g["lr"], g["hr"], g["tape"], g["dout"], self._scratch[1024:1025], on_bucket=boundary)
+                    finally:
+                        if state["open"] < len(graphs):         # an error left a capture open: close it before re-raising
+                            try:
+                                graphs[state["open"]].capture_end()
+                            except Exception:                   # noqa: BLE001
+                                pass
+                torch.cuda.current_stream(dev).wait_stream(side)
+                g["graphs"] = graphs
+            g["buckets"] = [grad_bucket(self.s, b) for b in range(_lib.GRAD_BUCKETS)]
             self._graphs[key] = g
         return g
 
     def step(self, lr_in: torch.Tensor, hr: torch.Tensor) -> torch.Tensor:
-        from .dp import sum_gradients_
+        from . import dp
         dev = lr_in.device
         B, _, H, W = lr_in.shape
         h, w = H // self.A, W // self.A
         L = _lib.lib()
+        exchange = dp.dp_active(self.group)
+        handles = []
+
+        def start_bucket(bucket, first, count):                # the all-reduce of a finished bucket, beside the rest of the backward
+            handles.append(dp.sum_gradients_start_(self.flat_grads[first:first + count], self.group))
+
         with torch.cuda.device(dev):
             loss = self._scratch[1024:1025]
             if self.use_graph:
-                g = self._graph_for(lr_in.contiguous().float(), hr.contiguous().float())
+                g = self._graph_for(lr_in.contiguous().float(), hr.contiguous().float(), bucketed=exchange)
                 g["lr"].copy_(lr_in)
                 g["hr"].copy_(hr)
-                g["graph"].replay()
+                for b, graph in enumerate(g["graphs"]):
+                    graph.replay()
+                    if exchange:
+                        start_bucket(b, *g["buckets"][b])
             else:
                 nb = tape_bytes(B, self.A, h, w, self.s)
                 if self._tape is None or self._tape.numel() != nb:
                     self._tape = torch.empty(nb, dtype=torch.uint8, device=dev)
-                self._fwd_loss_bwd(lr_in.contiguous().float(), hr.contiguous().float(), self._tape, torch.empty_like(hr), loss)
+                self._fwd_loss_bwd(lr_in.contiguous().float(), hr.contiguous().float(), self._tape, torch.empty_like(hr), loss,
+                                   on_bucket=start_bucket if exchange else None)
+            dp.sum_gradients_finish(handles)                   # the Adam kernel is ordered after the collectives
+            gscale = dp.grad_scale(self.group) if exchange else 1.0
             stream = torch.cuda.current_stream(dev).cuda_stream
-            gscale = sum_gradients_(self.flat_grads, self.group)          # the step's only collective
             self.t += 1
             _lib.check(L.lft_adam_step(self.flat_params.data_ptr(), self.flat_grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                        self.flat_params.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.t,

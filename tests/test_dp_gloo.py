@@ -131,3 +131,36 @@ def test_trainstep_broadcasts_rank0_weights():
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(0) and ret.get(1)
+
+
+def _bucket_worker(rank, world, port, ret):
+    """The bucketed form of the gradient exchange (what TrainStep.step drives from the backward pass's bucket callbacks):
+    three contiguous views of one flat buffer, each all-reduce started on its own, finished together -- must equal the
+    one-call sum, and dp_active / grad_scale must report the exchange."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        flat = torch.randn(1000, generator=g)
+        whole = flat.clone()
+        scale = dp.sum_gradients_(whole)
+        spans = [(600, 400), (100, 500), (0, 100)]                   # finished back to front, like the backward pass
+        handles = [dp.sum_gradients_start_(flat[a:a + n]) for a, n in spans]
+        dp.sum_gradients_finish(handles)
+        ret[rank] = bool(torch.equal(flat, whole)) and scale == 0.5 and dp.grad_scale() == 0.5 and dp.dp_active()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_gradient_sum():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(0) and ret.get(1)
+    assert not dp.dp_active() and dp.grad_scale() == 1.0             # no process group in this process

@@ -310,6 +310,24 @@ lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=0)).to(dev)
 hr = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).random((B, 1, A * h * s, A * w * s), dtype=np.float32)).to(dev)
 l0 = float(ts.step(lr, hr)); l1 = float(ts.step(lr, hr))
 assert np.isfinite(l0) and l1 < l0, (l0, l1)
+# bucketed exchange: the backward pass reports three gradient buckets; each one's ncclAllReduce is started while the next
+# bucket's kernels are enqueued (graph mode: one captured graph per bucket).  Must not change a bit against the plain step.
+def run(force, graph):
+    os.environ["LFT_DP_FORCE_COLLECTIVES"] = "1" if force else "0"
+    n = LFT.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=s))
+    n.load_state_dict({k: torch.from_numpy(v) for k, v in deterministic_state(64, s, seed=1, flavor="stress").items()})
+    t = T.TrainStep(n.to(dev).train(), lr=2e-4, graph=graph)
+    losses = [float(t.step(lr, hr)) for _ in range(3)]
+    if force and graph:
+        assert len(next(iter(t._graphs.values()))["graphs"]) == 3
+    return losses, t.flat_params.clone(), t.flat_grads.clone()
+plain = run(False, True)
+for force, graph in ((True, True), (True, False)):
+    got = run(force, graph)
+    assert got[0] == plain[0], (force, graph, got[0], plain[0])
+    assert torch.equal(got[1], plain[1]) and torch.equal(got[2], plain[2]), (force, graph)
+spans = sorted(T.grad_bucket(s, b) for b in range(3))
+assert spans[0][0] == 0 and all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(2)) and spans[2][0] + spans[2][1] == T.grad_floats(s)
 dist.barrier(); dist.destroy_process_group()
 print("RCCL_OK")
 """

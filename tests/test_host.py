@@ -58,7 +58,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.lib().lft_version() == 2
+    assert _lib.lib().lft_version() == 3
 
 
 def test_size_queries_and_argument_errors():
@@ -97,3 +97,31 @@ def test_training_and_metrics_size_queries_and_argument_errors():
     assert L.lft_view_metrics(1, 1, 1, 5, 8, 8, 2.0, 1, 1, 1, None) == -2                 # views smaller than the SSIM window
     assert L.lft_adam_step(1, 1, 1, 1, 10, 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, 0.0, None) == -1   # steps count from 1
     assert L.lft_adam_step(1, 1, 1, 1, 10, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, -0.1, None) == -1  # weight decay >= 0
+
+
+def test_gradient_buckets_tile_the_flat_buffer():
+    """lft_train_grad_bucket (host-only): the three buckets the backward pass reports are disjoint, contiguous and cover
+    the flat gradient buffer; bucket 0 (finished first) is the far end -- altblock.2, altblock.3, upsampling."""
+    import ctypes
+    from lft_amd.params import param_table
+    L = _lib.lib()
+    for s in (2, 4):
+        total = ctypes.c_size_t(0)
+        _lib.check(L.lft_train_grad_floats(s, ctypes.byref(total)), "grad_floats")
+        spans = []
+        for b in range(_lib.GRAD_BUCKETS):
+            first, count = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            _lib.check(L.lft_train_grad_bucket(s, b, ctypes.byref(first), ctypes.byref(count)), "grad_bucket")
+            spans.append((first.value, count.value))
+        assert spans[2][0] == 0 and spans[2][0] + spans[2][1] == spans[1][0] and spans[1][0] + spans[1][1] == spans[0][0]
+        assert spans[0][0] + spans[0][1] == total.value
+        off, starts = 0, {}
+        for name, shape, _ in param_table(64, s):
+            starts[name] = off
+            n = 1
+            for d in shape:
+                n *= d
+            off += n
+        assert spans[1][0] == starts["altblock.0.spa_trans.MLP.weight"]
+        assert spans[0][0] == starts["altblock.2.spa_trans.MLP.weight"]
+    assert L.lft_train_grad_bucket(2, 3, ctypes.byref(first), ctypes.byref(count)) != 0
