@@ -490,12 +490,18 @@ __global__ __launch_bounds__(64 * CT * NG) void k_ang_multi(const T* __restrict_
                 for (int i = 0; i < 16; ++i) m = fmaxf(m, S[j][i]);
             }
             m = xhalf_max(m);
-            float sum = 0.0f;
+            const f32x2 mm = {m, m};                               // register pairs: v_pk_add_f32 (as in k_ang)
+            f32x2 sum2 = {0.0f, 0.0f};
 #pragma unroll
             for (int j = 0; j < CT; ++j)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { S[j][i] = fast_exp2(S[j][i] - m); sum += S[j][i]; }
-            const float inv = 1.0f / xhalf_sum(sum);
+                for (int i = 0; i < 16; i += 2) {
+                    f32x2 d = f32x2{S[j][i], S[j][i + 1]} - mm;
+                    d[0] = fast_exp2(d[0]); d[1] = fast_exp2(d[1]);
+                    S[j][i] = d[0]; S[j][i + 1] = d[1];
+                    sum2 += d;
+                }
+            const float inv = 1.0f / xhalf_sum(sum2[0] + sum2[1]);
             const bool mine = (r >> 3) == (hd & 3);
 #pragma unroll
             for (int j = 0; j < CT; ++j)
