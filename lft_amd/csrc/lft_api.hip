@@ -130,10 +130,10 @@ WorkLayout work_layout(const Dims& d, int prec) {
 }
 
 // Dynamic LDS sizes (bytes) and the opt-in above the 64 KiB default (a workgroup may use all 160 KiB of a CU).
-template <typename T> size_t lds_conv64(int w) { return WRing<T, kConv64Chunk, kNwConv>::LDS_BYTES + ConvIn<T, kNwConv>::bytes(w) + kNwConv * TileIO<2, T>::BYTES; }
+template <typename T> size_t lds_conv64(int w) { return WRing<T, kConv64Chunk, kNwConv>::LDS_BYTES + ConvIn<T, kNwConv>::bytes(w) + kNwConv * TileIO<2, T>::BYTES + kConvZeroRow; }
 constexpr size_t kLdsParams = 1024;   // 256 LayerNorm floats
 template <typename T, int CH = kSpaChunk> size_t lds_spa1(int w) {      // the tile I/O scratch aliases the conv input tile, which must be large enough for it
-    return WRing<T, CH, kNwSpa1>::LDS_BYTES + std::max<size_t>(ConvIn<T, kNwSpa1>::bytes(w), (size_t)kNwSpa1 * TileIO<4, T>::BYTES) + kLdsParams;
+    return WRing<T, CH, kNwSpa1>::LDS_BYTES + std::max<size_t>(ConvIn<T, kNwSpa1>::bytes(w), (size_t)kNwSpa1 * TileIO<4, T>::BYTES) + kLdsParams + kConvZeroRow;
 }
 template <typename T> size_t lds_spa2() { return WRing<T, kSpaChunk, kNwSpa2>::LDS_BYTES + kLdsParams + kNwSpa2 * TileIO<4, T>::BYTES; }
 template <typename T> size_t lds_up() { return WRing<T, kUpChunk, kNwUp>::LDS_BYTES + kNwUp * TileIO<2, T>::BYTES; }

@@ -161,18 +161,26 @@ LFT_DEV void stage_conv_input(const T* __restrict__ img, int p0, int hw, int w, 
 LFT_DEV void wait_staged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // own DMA pieces and early loads landed
 
 // tl = token index inside the workgroup tile (0..127); (y, x) its image coordinates.
+// Taps that fall outside the image (per-view zero padding) read a row of zeros (`zero_row`, kConvZeroRow bytes the caller
+// cleared before publishing the tile) instead of being masked in registers: one select on the row address per tap
+// instead of one per fragment register (16 v_cndmask per tap).
+constexpr int kConvZeroRow = 256;
+LFT_DEV void clear_zero_row(char* zero_row) {                          // call before the barrier that publishes the input tile
+    if (threadIdx.x < kConvZeroRow / 16) store_raw16(zero_row + threadIdx.x * 16, raw16{0u, 0u, 0u, 0u});
+}
 template <int NT, typename T, int CH, int NW>
-LFT_DEV void conv3x3_tile(const char* lds_in, int tl, int y, int x, bool ok, int h, int w, int hh,
+LFT_DEV void conv3x3_tile(const char* lds_in, const char* zero_row, int tl, int y, int x, bool ok, int h, int w, int hh,
                           WRing<T, CH, NW>& ring, f32x16 (&acc)[NT]) {
     using CI = ConvIn<T, NW>;
+    static_assert(CI::ROW_BYTES <= kConvZeroRow, "zero row too short");
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         const int yy = y + dy, xx = x + dx;
         const bool inb = ok && yy >= 0 && yy < h && xx >= 0 && xx < w;
         const int slot = tl + w + 1 + dy * w + dx;
-        const char* row = lds_in + slot * CI::ROW_BYTES;
-        const int sw = CI::swz(slot);
+        const char* row = inb ? lds_in + slot * CI::ROW_BYTES : zero_row;
+        const int sw = inb ? CI::swz(slot) : 0;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             Frag<T> b;
@@ -182,7 +190,6 @@ LFT_DEV void conv3x3_tile(const char* lds_in, int tl, int y, int x, bool ok, int
                 b.lo = __builtin_bit_cast(f32x4, load_raw16(row + (((4 * ks + 2 * hh) ^ sw) * 16)));
                 b.hi = __builtin_bit_cast(f32x4, load_raw16(row + (((4 * ks + 2 * hh + 1) ^ sw) * 16)));
             }
-            if (!inb) b = frag_zero(T());
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) mma(ring.next(), b, acc[nt]);
         }
@@ -215,16 +222,18 @@ __global__ __launch_bounds__(64 * NW) void k_conv64(const T* __restrict__ in, T*
     const size_t tile_off = ((size_t)im * hw + min(t0, hw - 1)) * 64;
     char* lds_in = smem + WRing<T, kConv64Chunk, NW>::LDS_BYTES;
     char* scr = lds_in + ConvIn<T, NW>::bytes(w) + wave * TileIO<2, T>::BYTES;        // wave-private tile I/O scratch
+    char* zero_row = lds_in + ConvIn<T, NW>::bytes(w) + NW * TileIO<2, T>::BYTES;
     f32x16 rr[2];
     if (RES) load_tile<2, T>(res + tile_off, nvalid, lane, rr, scr);                  // first: its latency hides under the tile
     WRing<T, kConv64Chunk, NW> ring;
     ring.init(wstream, smem, 72);
     stage_conv_input<T, NW>(in + (size_t)im * hw * 64, p0, hw, w, lds_in);
+    clear_zero_row(zero_row);
     wait_staged();
     __syncthreads();                                                                 // ... and everybody else's
     f32x16 acc[2];
     zero_acc<2>(acc);
-    conv3x3_tile<2, T>(lds_in, tl, p / w, p % w, ok, h, w, hh, ring, acc);
+    conv3x3_tile<2, T>(lds_in, zero_row, tl, p / w, p % w, ok, h, w, hh, ring, acc);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll

@@ -53,11 +53,13 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
     if (!PE_ONLY) load_lane_major_raw<4, T>(petok + (size_t)((p0 >> 5) + wave) * 4096, lane, pe_raw);   // early, 8 coalesced loads
     char* lds_in = smem + WRing<T, CH, NW>::LDS_BYTES;
     float* lds_ln = reinterpret_cast<float*>(lds_in + max(ConvIn<T, NW>::bytes(w), NW * TileIO<4, T>::BYTES));   // the tile I/O scratch aliases the conv input
+    char* zero_row = reinterpret_cast<char*>(lds_ln) + 1024;           // behind the 256 LayerNorm floats
     raw16 lnv = raw16{0u, 0u, 0u, 0u};
     if (!PE_ONLY) lnv = params_load(ln, 256);                         // norm.{weight,bias}; ln is null in the pack-time PE_ONLY launch
     WRing<T, CH, NW> ring;
     ring.init(ws, smem, PE_ONLY ? 144 : 240);
     stage_conv_input<T, NW>(X + (size_t)im * hw * 64, p0, hw, w, lds_in);
+    clear_zero_row(zero_row);
     LFT_STAMP(12);
     wait_staged();
     LFT_STAMP(13);
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
     LFT_STAMP(1);
     f32x16 t[4];
     zero_acc<4>(t);
-    conv3x3_tile<4, T>(lds_in, tl, p / w, p % w, ok, h, w, hh, ring, t);
+    conv3x3_tile<4, T>(lds_in, zero_row, tl, p / w, p % w, ok, h, w, hh, ring, t);
     LFT_STAMP(2);
     if (PE_ONLY) {
         store_lane_major<4, T>(pe_out + (size_t)((p0 >> 5) + wave) * 4096, lane, t);   // lane-major table, one 32-token tile per wave
