@@ -92,8 +92,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, const float* __restrict__ w0,
                                                T* __restrict__ out, int B, int A, int h, int w) {
     // grid: x = 32-token groups of one view image, y = image (b, v).  32-bit index math only.
-    __shared__ float wl[576];                                        // the 64 x 9 weights, read 72 times per thread
-    for (int i = threadIdx.x; i < 576; i += 256) wl[i] = w0[i];
+    // The 64 x 9 weights, 72 of them per thread: the kernel was bound by these LDS reads (72 ds_read_b32 per thread, 2-way
+    // bank conflicts).  9 taps padded to 12 floats per channel = three 16-byte reads; channel groups 100 floats apart put the
+    // eight distinct addresses of a 16-lane group on disjoint banks.
+    __shared__ __attribute__((aligned(16))) float wl[8 * 100];
+    for (int i = threadIdx.x; i < 576; i += 256) {
+        const int ch = i / 9, t = i - ch * 9;
+        wl[(ch >> 3) * 100 + (ch & 7) * 12 + t] = w0[i];
+    }
     __syncthreads();
     const int hw = h * w, im = blockIdx.y, V = A * A;
     const int p = blockIdx.x * 32 + (threadIdx.x >> 3), cg = threadIdx.x & 7;
@@ -110,9 +116,14 @@ __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, con
     f32x4 o[2];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        float a = 0.0f;
+        const f32x4* wq = reinterpret_cast<const f32x4*>(wl + cg * 100 + c * 12);
+        const f32x4 w03 = wq[0], w47 = wq[1], w8 = wq[2];
+        float a = 0.0f;                                              // same order of additions as before: bit-identical results
 #pragma unroll
-        for (int t = 0; t < 9; ++t) a += wl[(cg * 8 + c) * 9 + t] * val[t];
+        for (int t = 0; t < 4; ++t) a += w03[t] * val[t];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a += w47[t] * val[4 + t];
+        a += w8[0] * val[8];
         o[c >> 2][c & 3] = a;
     }
     T* row = out + ((size_t)im * hw + p) * 64 + cg * 8;
