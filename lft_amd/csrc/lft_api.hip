@@ -315,7 +315,7 @@ int init_features(const void* packed, const PackedLayout& L, const float* lr, T*
     int rc;
     if ((rc = allow_lds(k_conv64<T, false>, lds, "k_conv64"))) return rc;
     if ((rc = allow_lds(k_conv64<T, true>, lds, "k_conv64"))) return rc;
-    k_conv0<T><<<dim3((unsigned)((d.hw + 31) / 32), (unsigned)nimg), 256, 0, st>>>(lr, at<float>(packed, L.conv0_w), x0, d.B, d.A, d.h, d.w);
+    k_conv0<T><<<dim3((unsigned)((d.hw + kConv0Tok - 1) / kConv0Tok), (unsigned)nimg), 256, 0, st>>>(lr, at<float>(packed, L.conv0_w), x0, d.B, d.A, d.h, d.w);
     LFT_LAUNCH_OK("k_conv0");
     k_conv64<T, false><<<nwg, 64 * kNwConv, lds, st>>>(x0, ta, nullptr, at<T>(packed, L.s_conv[0]), nimg, d.h, d.w);
     LFT_LAUNCH_OK("k_conv64");

@@ -88,10 +88,11 @@ __global__ void k_copy_f32(const float* __restrict__ src, float* __restrict__ ds
 // Reads the LR mosaic [B,1,A*h,A*w] (view (a1,a2) is the block at rows a1*h.., cols a2*w.. -- LFT.py:58),
 // writes channels-last tokens [B,V,h,w,64].  One thread = 8 channels of one token.
 // ------------------------------------------------------------------------------------------
+constexpr int kConv0Tok = 128;          // tokens per workgroup
 template <typename T>
 __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, const float* __restrict__ w0,
                                                T* __restrict__ out, int B, int A, int h, int w) {
-    // grid: x = 32-token groups of one view image, y = image (b, v).  32-bit index math only.
+    // grid: x = kConv0Tok-token groups of one view image, y = image (b, v).  32-bit index math only.
     // The 64 x 9 weights, 72 of them per thread: the kernel was bound by these LDS reads (72 ds_read_b32 per thread, 2-way
     // bank conflicts).  9 taps padded to 12 floats per channel = three 16-byte reads; channel groups 100 floats apart put the
     // eight distinct addresses of a 16-lane group on disjoint banks.
@@ -102,33 +103,55 @@ __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, con
     }
     __syncthreads();
     const int hw = h * w, im = blockIdx.y, V = A * A;
-    const int p = blockIdx.x * 32 + (threadIdx.x >> 3), cg = threadIdx.x & 7;
-    if (p >= hw) return;
-    const int b = im / V, v = im - b * V;
-    const int y = p / w, x = p - y * w, a1 = v / A, a2 = v - a1 * A;
+    const int cg = threadIdx.x & 7;
+    const int b = im / V, v = im - b * V, a1 = v / A, a2 = v - a1 * A;
     const float* img = lr + (size_t)b * (A * h) * (A * w) + (size_t)(a1 * h) * (A * w) + a2 * w;
-    float val[9];
+    // kConv0Tok tokens per workgroup, 32 per pass: the weight staging and the barrier above are paid once per 128 tokens
+    // (3 200 workgroups of 32 tokens spent most of their time in that prologue)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-        val[t] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[yy * (A * w) + xx] : 0.0f;
+    for (int pass = 0; pass < kConv0Tok / 32; ++pass) {
+        const int p = blockIdx.x * kConv0Tok + pass * 32 + (threadIdx.x >> 3);
+        if (p >= hw) return;
+        const int y = p / w, x = p - y * w;
+        // branch-free: all nine taps are loaded from clamped (readable) positions, then selected -- a conditional load is a
+        // masked branch per tap, nine dependent round trips instead of nine loads in flight.  The empty asm names all nine
+        // values at once: it keeps hipcc from sinking the loads back under their conditions.
+        float val[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            val[t] = img[min(max(yy, 0), h - 1) * (A * w) + min(max(xx, 0), w - 1)];
+        }
+        asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]), "+v"(val[8]));
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            val[t] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? val[t] : 0.0f;
+        }
+        f32x4 o[2];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4* wq = reinterpret_cast<const f32x4*>(wl + cg * 100 + c * 12);
+            const f32x4 w03 = wq[0], w47 = wq[1], w8 = wq[2];
+            float a = 0.0f;                                              // same order of additions as before: bit-identical results
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a += w03[t] * val[t];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a += w47[t] * val[4 + t];
+            a += w8[0] * val[8];
+            o[c >> 2][c & 3] = a;
+        }
+        T* row = out + ((size_t)im * hw + p) * 64 + cg * 8;
+        if constexpr (sizeof(T) == 2) {                              // one 16-byte store per thread: a wave writes 1 KiB of whole lines
+            typename H16<T>::v8 v;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = (T)o[c >> 2][c & 3];
+            store_raw16(reinterpret_cast<char*>(row), __builtin_bit_cast(raw16, v));
+        } else {
+            store4(row, o[0]);
+            store4(row + 4, o[1]);
+        }
     }
-    f32x4 o[2];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const f32x4* wq = reinterpret_cast<const f32x4*>(wl + cg * 100 + c * 12);
-        const f32x4 w03 = wq[0], w47 = wq[1], w8 = wq[2];
-        float a = 0.0f;                                              // same order of additions as before: bit-identical results
-#pragma unroll
-        for (int t = 0; t < 4; ++t) a += w03[t] * val[t];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) a += w47[t] * val[4 + t];
-        a += w8[0] * val[8];
-        o[c >> 2][c & 3] = a;
-    }
-    T* row = out + ((size_t)im * hw + p) * 64 + cg * 8;
-    store4(row, o[0]);
-    store4(row + 4, o[1]);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -381,7 +381,7 @@ int train_forward(const float* const* P, const float* lr, float* out, float* tap
     k_pe_plain<<<blocks_for(std::max(d.V, d.hw) * 64, 256), 256, 0, st>>>(c.F(T.pe_ang), c.F(T.pe_spa), d.V, d.h, d.w);
     LFT_LAUNCH_OK("k_pe_plain");
     // conv_init0, conv_init + residual (LFT.py:65-66)
-    k_conv0<float><<<dim3((unsigned)((d.hw + 31) / 32), (unsigned)nimg), 256, 0, st>>>(lr, P[P_CONV0], c.F(T.x0), d.B, d.A, d.h, d.w);
+    k_conv0<float><<<dim3((unsigned)((d.hw + kConv0Tok - 1) / kConv0Tok), (unsigned)nimg), 256, 0, st>>>(lr, P[P_CONV0], c.F(T.x0), d.B, d.A, d.h, d.w);
     LFT_LAUNCH_OK("k_conv0");
     TRY(lin_fwd(c, VW_CONV_F + 0, c.F(T.x0), 2, nullptr, c.F(T.c1), N));
     TRY(lin_fwd(c, VW_CONV_F + 1, c.F(T.c1), 2, nullptr, c.F(T.c2), N));
