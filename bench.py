@@ -281,12 +281,20 @@ def main():
             note("spawning: " + " ".join(cmd))
             raise SystemExit(subprocess.call(cmd))
         args.gpus = world
+    # LFT_BENCH_ONE_GPU_REHEARSAL=1: all ranks share cuda:0 and talk over gloo -- exercises the spawn / barrier / max-over-ranks
+    # path of `--gpus N` on a one-GPU box (tests/test_gpu_module.py); the number it prints is not a scaling measurement.
+    rehearsal = os.environ.get("LFT_BENCH_ONE_GPU_REHEARSAL", "0") == "1" and world > 1
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from lft_amd.params import deterministic_state, synthetic_lr
     from model import LFT
@@ -325,7 +333,7 @@ def main():
         dt = time.perf_counter() - t0
     assert bool(torch.isfinite(out).all()) or os.environ.get("LFT_BENCH_EXPERIMENT")      # knock-out builds of tools/ab_build.py compute garbage
     note(f"rank {rank}: {args.steps} steps in {dt:.3f} s")
-    dt = dp.barrier_max_seconds(dt, dev)          # MAX over ranks
+    dt = dp.barrier_max_seconds(dt, torch.device("cpu") if rehearsal else dev)          # MAX over ranks
 
     result = None
     if rank == 0:
@@ -364,6 +372,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            **({"rehearsal": f"{world} ranks share one GPU over gloo: not a scaling measurement"} if rehearsal else {}),
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"LFT {A}x{A} angRes {S}xSR inference, batch={args.batch} per GPU, {H}x{W} LR patches",
                        "global_batch": world * args.batch, "parallelism": f"dp{world} (independent shards)",

@@ -180,3 +180,25 @@ def test_graph_refuses_replay_after_weights_change():
             g(lr)
         g2 = GraphedForward(net, lr)
         assert torch.equal(g2(lr), b)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` run plainly must start its two ranks itself (torch.distributed.run as a child of a parent
+    that never touched the GPU), time with the barrier / max-over-ranks protocol and print ONE JSON line for the job.  On the
+    one-GPU test box the ranks share cuda:0 over gloo (LFT_BENCH_ONE_GPU_REHEARSAL); on a node the same path uses RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LFT_BENCH_ONE_GPU_REHEARSAL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 10 and j["config"]["global_batch"] == 8 and j["scaling"] == "weak"
+    assert j["value"] > 0 and "roofline" in j and "rehearsal" in j
+    assert abs(j["value"] - 2 * 4 * 10 / (j["ms_per_step"] * 10 / 1e3)) < 1e-6 * j["value"]
