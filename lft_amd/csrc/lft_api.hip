@@ -333,10 +333,19 @@ int ang_multi(const void* packed, const PackedLayout& L, int l, const T* in, T* 
     const size_t lds = (WLDS ? 64 * FB : 0) + 1024 + (size_t)NG * CT * 8 * FB + (size_t)NG * CT * TileIO<2, T>::BYTES;
     const int npix = d.B * d.hw;
     int rc;
-    if ((rc = allow_lds(k_ang_multi<T, CT, WLDS, NG>, lds, "k_ang_multi"))) return rc;
     const unsigned grid = std::min<unsigned>(blocks_for(npix, NG), 256u * (unsigned)std::max<size_t>(1, kMaxLds / lds));
-    k_ang_multi<T, CT, WLDS, NG><<<grid, 64 * CT * NG, lds, st>>>(in, out, at<T>(packed, L.s_ang[l]), at<float>(packed, L.ln_ang[l]),
-                                                                 at<float>(packed, L.ang_pe), d.V, d.hw, npix);
+    // score registers of the last key tile that can hold a view: register i covers rows acc_row(i, 0) and acc_row(i, 1) = +4
+    const int rows_last = d.V - 32 * (CT - 1);                              // 1 .. 32 by the choice of CT
+#define LFT_LAUNCH_ANGM(LL)                                                                                             \
+    do {                                                                                                                \
+        if ((rc = allow_lds(k_ang_multi<T, CT, WLDS, NG, LL>, lds, "k_ang_multi"))) return rc;                            \
+        k_ang_multi<T, CT, WLDS, NG, LL><<<grid, 64 * CT * NG, lds, st>>>(in, out, at<T>(packed, L.s_ang[l]),              \
+                                                                         at<float>(packed, L.ln_ang[l]), at<float>(packed, L.ang_pe), d.V, d.hw, npix); \
+    } while (0)
+    if (rows_last <= 17) LFT_LAUNCH_ANGM(9);          // e.g. 9 x 9 = 81 views: 17 rows in the third tile
+    else if (rows_last <= 25) LFT_LAUNCH_ANGM(13);
+    else LFT_LAUNCH_ANGM(16);
+#undef LFT_LAUNCH_ANGM
     LFT_LAUNCH_OK("k_ang");
     return 0;
 }

@@ -436,7 +436,9 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
 // ------------------------------------------------------------------------------------------
 // NG positions share one workgroup (NG * CT waves) and therefore one LDS copy of the weights: more waves per CU for the
 // same LDS (9x9, bf16: 2 x 3 waves and 113 KiB instead of 3 waves and 89 KiB).  All groups run the loop in lock-step.
-template <typename T, int CT, bool WLDS, int NG>
+// LASTLIVE: score registers of the LAST key tile that can hold an existing view (as NLIVE in k_ang): 9 x 9 views on three
+// tiles leave 17 rows in the last one -- registers 9 .. 15 are never a view and are skipped at compile time.
+template <typename T, int CT, bool WLDS, int NG, int LASTLIVE = 16>
 __global__ __launch_bounds__(64 * CT * NG) void k_ang_multi(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ ws,
                                                             const float* __restrict__ ln, const float* __restrict__ pe,
                                                             int V, int hw, int npix) {
@@ -467,6 +469,10 @@ __global__ __launch_bounds__(64 * CT * NG) void k_ang_multi(const T* __restrict_
     const bool ok = view < V;
     const int nrows = max(0, min(32, V - wave * 32));                // views of this column tile
     const size_t vstride = (size_t)hw * 64 * sizeof(T);              // one view to the next, same position
+    // 0 / -inf start value of the LAST key tile's scores (the host picks CT = ceil(V / 32): every earlier tile is full)
+    f32x16 negmask;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negmask[i] = (32 * (CT - 1) + acc_row(i, hh) >= V) ? -INFINITY : 0.0f;
     for (int base = blockIdx.x * NG; base < npix; base += gridDim.x * NG) {
         asm volatile("" ::: "memory");
         const bool active = base + grp < npix;                        // a trailing group repeats the last position and stores nothing
@@ -483,12 +489,12 @@ __global__ __launch_bounds__(64 * CT * NG) void k_ang_multi(const T* __restrict_
             for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
             add_acc_raw<2, float>(n, pr, ok);
         }
-        layernorm_acc<2>(n, lds_ln, lds_ln + 64, hh);
+        layernorm_acc<2, sizeof(T) == 2>(n, lds_ln, lds_ln + 64, hh);
         Frag<T> nf[4], xf[4];
         acc_frags<2, T>(n, nf);
         acc_frags<2, T>(x, xf);
         f32x16 q[2], o[2];
-        zero_acc<2>(q); zero_acc<2>(o);
+        zero_acc<2>(q);
         {
             f32x16 k[2], v[2];
             zero_acc<2>(k); zero_acc<2>(v);
@@ -526,33 +532,46 @@ __global__ __launch_bounds__(64 * CT * NG) void k_ang_multi(const T* __restrict_
             float m = -INFINITY;
 #pragma unroll
             for (int j = 0; j < CT; ++j) {
+                const int live = j == CT - 1 ? LASTLIVE : 16;
+                if (j == CT - 1) S[j] = negmask;
+                else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) S[j][i] = (32 * j + acc_row(i, hh) >= V) ? -INFINITY : 0.0f;
+                    for (int i = 0; i < 16; ++i) S[j][i] = 0.0f;
+                }
                 mma(frag_half(frag_from_pieces(lds_kv + (j * 8 + nt * 2 + s) * FB, lane, T()), half), qf, S[j]);   // S^T[kv, q]
 #pragma unroll
-                for (int i = 0; i < 16; ++i) m = fmaxf(m, S[j][i]);
+                for (int i = 0; i < live; ++i) m = fmaxf(m, S[j][i]);
             }
             m = xhalf_max(m);
             const f32x2 mm = {m, m};                               // register pairs: v_pk_add_f32 (as in k_ang)
             f32x2 sum2 = {0.0f, 0.0f};
 #pragma unroll
-            for (int j = 0; j < CT; ++j)
+            for (int j = 0; j < CT; ++j) {
+                const int live = j == CT - 1 ? LASTLIVE : 16;
 #pragma unroll
-                for (int i = 0; i < 16; i += 2) {
+                for (int i = 0; i + 1 < live; i += 2) {
                     f32x2 d = f32x2{S[j][i], S[j][i + 1]} - mm;
                     d[0] = fast_exp2(d[0]); d[1] = fast_exp2(d[1]);
                     S[j][i] = d[0]; S[j][i + 1] = d[1];
                     sum2 += d;
                 }
-            const float inv = 1.0f / xhalf_sum(sum2[0] + sum2[1]);
-            const bool mine = (r >> 3) == (hd & 3);
+                if (live & 1) { S[j][live - 1] = fast_exp2(S[j][live - 1] - m); sum2[0] += S[j][live - 1]; }
+#pragma unroll
+                for (int i = live; i < 16; ++i) S[j][i] = 0.0f;     // rows that are no view for any lane
+            }
+            const float inv = sizeof(T) == 2 ? fast_rcp(xhalf_sum(sum2[0] + sum2[1])) : 1.0f / xhalf_sum(sum2[0] + sum2[1]);
+            // O^T of this head in a fresh accumulator (all 32 channel rows of the product are computed, the head's own 8 rows =
+            // registers 4*(hd&3)..+3 are kept): cheaper than zeroing the other heads' channels of V per head and fragment
+            f32x16 oh;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oh[i] = 0.0f;
 #pragma unroll
             for (int j = 0; j < CT; ++j)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
-                    mma(frag_select<T>(mine, frag_from_pieces(lds_kv + (j * 8 + 4 + nt * 2 + s2) * FB, lane, T())), acc_to_frag(S[j], s2, T()), o[nt]);
+                    mma(frag_from_pieces(lds_kv + (j * 8 + 4 + nt * 2 + s2) * FB, lane, T()), acc_to_frag(S[j], s2, T()), oh);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[nt][4 * (hd & 3) + i] *= inv;
+            for (int i = 0; i < 4; ++i) o[nt][4 * (hd & 3) + i] = oh[4 * (hd & 3) + i] * inv;
         }
         Frag<T> of[4];
         acc_frags<2, T>(o, of);
