@@ -797,6 +797,44 @@ LFT_DEV float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
 LFT_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 template <int NT, bool FAST = false>
 LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* gamma, const float* beta, int h) {
+    if constexpr (FAST) {
+        // 16-bit paths: every pass on register pairs (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32), the centred value kept
+        // from the variance pass, gamma folded into the scale: 2.5 vector instructions per element instead of 6 -- these
+        // kernels are bound by vector-instruction issue.  ((x - mean) * (rstd * gamma) + beta: last-bit differences from the
+        // exact form below, far inside the 16-bit operand rounding that follows.)
+        f32x2 s2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) s2 += f32x2{a[nt][i], a[nt][i + 1]};
+        const float mean = xhalf_sum(s2[0] + s2[1]) * (1.0f / (NT * 32));
+        const f32x2 mean2 = {mean, mean};
+        f32x2 q2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2 d = f32x2{a[nt][i], a[nt][i + 1]} - mean2;
+                q2 = __builtin_elementwise_fma(d, d, q2);
+                a[nt][i] = d[0]; a[nt][i + 1] = d[1];
+            }
+        const float rstd = __builtin_amdgcn_rsqf(xhalf_sum(q2[0] + q2[1]) * (1.0f / (NT * 32)) + LFT_LN_EPS);
+        const f32x2 rstd2 = {rstd, rstd};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 gm = __builtin_bit_cast(f32x4, load_raw16(reinterpret_cast<const char*>(gamma + 32 * nt + 8 * g + 4 * h)));
+                const f32x4 bt = __builtin_bit_cast(f32x4, load_raw16(reinterpret_cast<const char*>(beta + 32 * nt + 8 * g + 4 * h)));
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const f32x2 sc = f32x2{gm[j], gm[j + 1]} * rstd2;
+                    const f32x2 o = __builtin_elementwise_fma(f32x2{a[nt][4 * g + j], a[nt][4 * g + j + 1]}, sc, f32x2{bt[j], bt[j + 1]});
+                    a[nt][4 * g + j] = o[0]; a[nt][4 * g + j + 1] = o[1];
+                }
+            }
+        return;
+    }
     float s = 0.0f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
