@@ -21,7 +21,26 @@
 #include <stdint.h>
 
 typedef __bf16 bf16_t;
+// Register pairs for the vector-instruction-bound phases.  LFT_PK = 1: a real 2-vector (v_pk_add_f32 / v_pk_mul_f32 /
+// v_pk_fma_f32: one instruction per pair); 0: two scalars with the same interface.
+#ifndef LFT_PK
+#define LFT_PK 1
+#endif
+#if LFT_PK
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 p2_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+struct f32x2 {
+    float v[2];
+    __device__ __forceinline__ float& operator[](int i) { return v[i]; }
+    __device__ __forceinline__ const float& operator[](int i) const { return v[i]; }
+};
+__device__ __forceinline__ f32x2 operator-(f32x2 a, f32x2 b) { return f32x2{a.v[0] - b.v[0], a.v[1] - b.v[1]}; }
+__device__ __forceinline__ f32x2 operator+(f32x2 a, f32x2 b) { return f32x2{a.v[0] + b.v[0], a.v[1] + b.v[1]}; }
+__device__ __forceinline__ f32x2 operator*(f32x2 a, f32x2 b) { return f32x2{a.v[0] * b.v[0], a.v[1] * b.v[1]}; }
+__device__ __forceinline__ f32x2& operator+=(f32x2& a, f32x2 b) { a.v[0] += b.v[0]; a.v[1] += b.v[1]; return a; }
+__device__ __forceinline__ f32x2 p2_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{__builtin_fmaf(a.v[0], b.v[0], c.v[0]), __builtin_fmaf(a.v[1], b.v[1], c.v[1])}; }
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -815,7 +834,7 @@ LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* gamma, const float* bet
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
                 const f32x2 d = f32x2{a[nt][i], a[nt][i + 1]} - mean2;
-                q2 = __builtin_elementwise_fma(d, d, q2);
+                q2 = p2_fma(d, d, q2);
                 a[nt][i] = d[0]; a[nt][i + 1] = d[1];
             }
         const float rstd = __builtin_amdgcn_rsqf(xhalf_sum(q2[0] + q2[1]) * (1.0f / (NT * 32)) + LFT_LN_EPS);
@@ -829,7 +848,7 @@ LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* gamma, const float* bet
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
                     const f32x2 sc = f32x2{gm[j], gm[j + 1]} * rstd2;
-                    const f32x2 o = __builtin_elementwise_fma(f32x2{a[nt][4 * g + j], a[nt][4 * g + j + 1]}, sc, f32x2{bt[j], bt[j + 1]});
+                    const f32x2 o = p2_fma(f32x2{a[nt][4 * g + j], a[nt][4 * g + j + 1]}, sc, f32x2{bt[j], bt[j + 1]});
                     a[nt][4 * g + j] = o[0]; a[nt][4 * g + j + 1] = o[1];
                 }
             }

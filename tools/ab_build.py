@@ -20,7 +20,7 @@ for name, flags in variants:
     so = os.path.join(outdir, f"liblft_{name}.so")
     if os.path.exists(so) and not build_only:
         continue
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + [f for f in flags.split(",") if f] + \
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-schedule-relaxed-occupancy=true", "-fPIC", "-shared"] + [f for f in flags.split(",") if f] + \
           [os.path.join(ROOT, "lft_amd/csrc/lft_api.hip"), "-o", so]
     procs.append((name, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
     if len(procs) >= 4:
