@@ -39,20 +39,49 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -amdgpu-schedule-relaxed-occupancy: the kernels' occupancy is set by their LDS footprint and launch bounds, so the
-    # scheduler may spend registers on a better instruction order (+1.2 %, k_spa1 43 -> 41 us event-timed); it changes no
-    # arithmetic.  (-fno-slp-vectorize would add another 1.4 % -- hipcc's SLP pass packs neighbouring scalar f32 operations
-    # into v_pk_*_f32, which issue slower beside MFMAs -- but it also changes which multiply-adds of the fp32 TRAINING
-    # kernels are contracted, enough to flip a ReLU unit in the independent gradient check; not used.)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-schedule-relaxed-occupancy=true",
-           "-fPIC", "-shared", os.path.join(CSRC, "lft_api.hip"), "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise LftError("hipcc failed:\n" + r.stdout + r.stderr)
+    for cmd in build_commands(hipcc, LIB_PATH):
+        if verbose:
+            print(" ".join(cmd))
+    compile_and_link(hipcc, LIB_PATH)
     return LIB_PATH
 
+
+# Flags of both translation units (lft_api.hip compiles as LFT_TU=1, the inference side, and LFT_TU=2, the training step).
+# -amdgpu-schedule-relaxed-occupancy: the kernels' occupancy is set by their LDS footprint and launch bounds, so the
+#   scheduler may spend registers on a better instruction order (+1.2 %, k_spa1 43 -> 41 us event-timed); no arithmetic changes.
+# -fno-slp-vectorize (inference unit only): hipcc's SLP pass packs neighbouring scalar f32 operations into v_pk_*_f32, which
+#   issue slower beside MFMAs than the two scalar instructions (+1.4 %).  The training unit keeps the default: SLP also decides
+#   which of its fp32 multiply-adds are contracted, and the step's last-bit behaviour is pinned by the gradient fixtures.
+COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-schedule-relaxed-occupancy=true", "-fPIC"]
+UNIT_FLAGS = {1: ["-fno-slp-vectorize"], 2: []}
+
+
+def _objects(lib_path):
+    d = os.path.join(os.path.dirname(lib_path), "_build")
+    return d, {tu: os.path.join(d, os.path.basename(lib_path) + f".tu{tu}.o") for tu in UNIT_FLAGS}
+
+
+def build_commands(hipcc, lib_path, extra=()):
+    _, objs = _objects(lib_path)
+    src = os.path.join(CSRC, "lft_api.hip")
+    cmds = [[hipcc, *COMMON_FLAGS, *UNIT_FLAGS[tu], *extra, f"-DLFT_TU={tu}", "-c", src, "-o", objs[tu]] for tu in sorted(objs)]
+    cmds.append([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *[objs[tu] for tu in sorted(objs)], "-o", lib_path])
+    return cmds
+
+
+def compile_and_link(hipcc, lib_path, extra=()):
+    """Both units in parallel, then the link; raises LftError with the compiler output on failure."""
+    d, _ = _objects(lib_path)
+    os.makedirs(d, exist_ok=True)
+    cmds = build_commands(hipcc, lib_path, extra)
+    procs = [subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for c in cmds[:-1]]
+    outs = [p.communicate()[0] for p in procs]
+    for p, o, c in zip(procs, outs, cmds):
+        if p.returncode != 0:
+            raise LftError("hipcc failed: " + " ".join(c) + "\n" + o)
+    r = subprocess.run(cmds[-1], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise LftError("link failed:\n" + r.stdout + r.stderr)
 
 _SIGS = {
     "lft_version": (c_int, []),

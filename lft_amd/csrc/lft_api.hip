@@ -1,10 +1,17 @@
 // lft_api.hip -- C ABI of liblft_hip.so (see include/lft_hip.h): buffer layouts, weight packing plan,
 // kernel launches.  Host-side code only enqueues work on the caller's stream.
+//
+// The library is built from this file as TWO translation units with different compiler flags (lft_amd/_lib.py):
+//   LFT_TU == 1   inference, scene tiling, metrics, debug entry points   -- with -fno-slp-vectorize: hipcc's SLP pass packs
+//                 neighbouring scalar f32 operations into v_pk_*_f32, which issue slower beside MFMAs than the two scalar
+//                 instructions (+1.4 % on the bench without it; the kernels pack explicitly, f32x2, where that was measured to pay)
+//   LFT_TU == 2   the fp32 training step -- default flags: the SLP pass also decides which of its multiply-adds are
+//                 contracted, and the step's last-bit behaviour is pinned by the gradient fixtures
+//   LFT_TU == 0   everything in one unit (tools, resource reports).
+// Every kernel and helper is local to its unit (anonymous namespace); the units share only the error buffer.
 #include "../../include/lft_hip.h"
-#include "lft_kernels_a.cuh"
-#include "lft_kernels_b.cuh"
-#include "lft_metrics.cuh"
-#include "lft_train.cuh"     // training kernels; the fp32 inference path shares their LDS-tiled window attention
+#include <hip/hip_runtime.h>
+#include <stdint.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -14,9 +21,25 @@
 #include <utility>
 #include <vector>
 
-namespace {
+#ifndef LFT_TU
+#define LFT_TU 0
+#endif
 
-thread_local char g_err[512] = "";
+namespace {
+#include "lft_kernels_a.cuh"
+#include "lft_kernels_b.cuh"
+#include "lft_metrics.cuh"
+#include "lft_train.cuh"     // training kernels; the fp32 inference path shares their LDS-tiled window attention
+}  // namespace
+
+#if LFT_TU == 2
+extern thread_local char lft_g_err[512];
+#else
+__attribute__((visibility("hidden"))) thread_local char lft_g_err[512] = "";
+#endif
+#define g_err lft_g_err
+
+namespace {
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -517,6 +540,7 @@ int kernel_time_impl(const char* name, const void* packed, void* ws, const Dims&
 // ================================================================================ C ABI
 extern "C" {
 
+#if LFT_TU != 2
 int lft_version(void) { return LFT_ABI_VERSION; }
 const char* lft_last_error(void) { return g_err; }
 
@@ -745,6 +769,8 @@ int lft_view_metrics(const float* label, const float* out, int B, int A, int h, 
     return 0;
 }
 
+#endif  // LFT_TU != 2
+#if LFT_TU != 1
 // ================================================================================ training (fp32)
 int lft_train_tape_bytes(int B, int A, int h, int w, int s, size_t* out_bytes) {
     Dims d; int rc;
@@ -848,4 +874,5 @@ int lft_adam_step(float* p, const float* g, float* m, float* v, long long n, flo
     return 0;
 }
 
+#endif  // LFT_TU != 1
 }  // extern "C"

@@ -15,20 +15,16 @@ build_only = bool(args) and args[0] == "--build"
 if build_only:
     args = args[1:]
 variants = [a.split(":", 1) for a in args] or [["base", ""]]
-procs = []
+sys.path.insert(0, ROOT)
+from lft_amd import _lib
 for name, flags in variants:
     so = os.path.join(outdir, f"liblft_{name}.so")
     if os.path.exists(so) and not build_only:
         continue
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-schedule-relaxed-occupancy=true", "-fPIC", "-shared"] + [f for f in flags.split(",") if f] + \
-          [os.path.join(ROOT, "lft_amd/csrc/lft_api.hip"), "-o", so]
-    procs.append((name, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
-    if len(procs) >= 4:
-        for n, p in procs:
-            if p.wait() != 0: raise SystemExit(f"build of {n} failed")
-        procs = []
-for n, p in procs:
-    if p.wait() != 0: raise SystemExit(f"build of {n} failed")
+    try:
+        _lib.compile_and_link("/opt/rocm/bin/hipcc", so, extra=[f for f in flags.split(",") if f])     # the library's own two-unit build + the variant's flags
+    except _lib.LftError as e:
+        raise SystemExit(f"build of {name} failed\n{str(e)[-2000:]}")
 if build_only:
     raise SystemExit(0)
 extra = os.environ.get("AB_BENCH_ARGS", "").split()
