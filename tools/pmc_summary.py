@@ -5,7 +5,7 @@ rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        m = re.match(r"(?:void )?(?:_Z\d+)?(k_[a-z0-9_]+)", name)
+        m = re.search(r"(k_[a-z0-9_]+)", name)                          # mangled or demangled, with or without (anonymous namespace)
         short = m.group(1) if m else name[:30]
         if "IfL" in name or "If" in name.split("E")[0][-3:]: short += "<f32>"
         rows[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
