@@ -14,8 +14,9 @@ Prints ONE JSON line on rank 0 with the extra objects
                  back between two HIP events on the launch stream (lft_kernel_time: no event between launches, so it is
                  comparable with the rocprofv3 kernel trace under profiles/).  `traffic` = HBM-side bytes per launch from the
                  committed PMC passes, only when they were taken on the very sources that are being timed (`source_hash`).
-  parity_path  : the exact-fp32 MFMA path (the one that meets BASELINE.json's 1e-3 relative tolerance), same workload, same
-                 run: patches/s, and both paths' measured error against the CPU oracle on one patch.
+  parity_path  : the paths that meet BASELINE.json's 1e-3 relative tolerance, same workload, same run: the fp16 path (the
+                 headline kernels with IEEE-half operands and tensors) with patches/s and its measured error against the CPU
+                 oracle on one patch, the headline path's error beside it, and `exact_fp32` (the exact-fp32 MFMA path).
   train        : BASELINE configs[2] on this GPU (A5, 2x, batch 8, Adam; one process = no all-reduce partner): ms/step, patches/s.
   cpu_baseline : the CPU oracle (a port of the reference's operator sequence, oracle/lft_oracle.py) timed on
                  this node's host cores on a bounded sample of the same workload (rank 0, N=1 only).
