@@ -17,7 +17,9 @@
  *  - prec selects the MFMA operand type: LFT_PREC_F32 = exact fp32 (v_mfma_f32_32x32x2_f32),
  *    LFT_PREC_BF16 = bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16), LFT_PREC_F16 = IEEE half operands /
  *    fp32 accumulate (v_mfma_f32_32x32x16_f16: same kernels, layouts and speed as bf16, 11 significant bits instead
- *    of 8, but a range of 65504 -- activations beyond it become inf, which the caller sees in the output).
+ *    of 8, but a range of 65504 -- activations beyond it become inf; every such event reaches a LayerNorm or the output as
+ *    inf / NaN, where the kernels set a sticky flag in the workspace that lft_status_read reports: an overflow is a loud error,
+ *    not a silently wrong image).
  *    Activations between kernels are stored in the same type (float, __bf16 or _Float16, channels-last [B, A*A, h, w, C]).
  *  - Shapes: A = angRes (A*A <= 128 views; 5x5 and 9x9 are the tested ones), h x w = LR view size, s = scale factor (2 or 4),
  *    channels fixed to 64 (reference option.py --channels default, LFT.py:11).
@@ -31,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LFT_ABI_VERSION 3
+#define LFT_ABI_VERSION 4
 #define LFT_PREC_F32 0
 #define LFT_PREC_BF16 1
 #define LFT_PREC_F16 2
@@ -45,6 +47,10 @@ extern "C" {
 #define LFT_ERR_ARG (-1)         /* null pointer / bad enum */
 #define LFT_ERR_SHAPE (-2)       /* shape outside what this build supports */
 #define LFT_ERR_UNSUPPORTED (-3) /* valid for the reference, not implemented here yet */
+#define LFT_ERR_CALLBACK (-4)    /* a caller-supplied callback asked to stop (lft_train_backward_buckets) */
+/* Returned by lft_status_read (never by the enqueue-only calls): a non-finite activation or output value was seen since the last
+ * lft_status_reset -- on the LFT_PREC_F16 path that is what a range overflow (|x| > 65504) turns into. */
+#define LFT_STATUS_NONFINITE 1001
 
 int lft_version(void);
 const char* lft_last_error(void);
@@ -64,6 +70,17 @@ int lft_pack_weights(const float* const* params, int nparams, void* packed,
 /* get_model.forward (reference LFT.py:52-83).  lr: fp32 [B,1,A*h,A*w]; out: fp32 [B,1,A*h*s,A*w*s]. */
 int lft_forward(const void* packed, const float* lr, float* out, void* workspace,
                 int B, int A, int h, int w, int s, int prec, void* stream);
+
+/* Sticky status word of a workspace (its last 256 bytes).  The kernels of lft_forward / the per-stage entry points that take a
+ * workspace set bit 0 when a token's LayerNorm variance or an output pixel is not finite (inf / NaN): an fp16 range overflow
+ * anywhere in the network, or non-finite input data.  Nothing clears it but lft_status_reset, so one read covers every
+ * forward since the last reset -- also graph replays, which the host never sees individually.
+ *   lft_status_reset: enqueue the clearing of the word on `stream` (call once after allocating a workspace, and after a read
+ *                     that reported something).
+ *   lft_status_read : copy the word to *host_flags (may be NULL), SYNCHRONISES `stream`; returns 0 when clear,
+ *                     LFT_STATUS_NONFINITE when set (lft_last_error() names the cause), or an error code. */
+int lft_status_reset(void* workspace, int B, int A, int h, int w, int s, int prec, void* stream);
+int lft_status_read(const void* workspace, int B, int A, int h, int w, int s, int prec, void* stream, unsigned* host_flags);
 
 /* Profiling aid, NOT for the hot path: same as lft_forward but records a HIP event on `stream` after every
  * kernel, SYNCHRONISES the stream, and returns per-kernel milliseconds (host arrays ms_out / names_out of
@@ -135,10 +152,11 @@ int lft_train_backward(const float* const* params, int nparams, const float* lr,
  * kernel writing that range has been enqueued on `stream` (the weight-gradient side stream joined).  The caller orders a
  * communication stream after `stream` there and starts the bucket's all-reduce, which then runs beside the kernels of the
  * remaining buckets; or, while capturing, ends one graph and begins the next (lft_amd/train.py does the latter).  Nothing
- * enqueued after the callback touches the bucket's range.  lft_train_backward is this function without notifications;
+ * enqueued after the callback touches the bucket's range.  The callback returns 0 to continue; any other value stops the pass
+ * right there (nothing further is enqueued) and the call returns LFT_ERR_CALLBACK -- e.g. a failed collective or capture.  lft_train_backward is this function without notifications;
  * both produce identical bits.  lft_train_grad_bucket gives the ranges (floats) without running anything. */
 #define LFT_GRAD_BUCKETS 3
-typedef void (*lft_bucket_fn)(void* user, int bucket, size_t first_float, size_t n_floats);
+typedef int (*lft_bucket_fn)(void* user, int bucket, size_t first_float, size_t n_floats);
 int lft_train_backward_buckets(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
                                int B, int A, int h, int w, int s, int math, void* stream, void* side_stream,
                                lft_bucket_fn on_bucket, void* user);

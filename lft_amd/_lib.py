@@ -14,6 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LFT_LIB_PATH") or os.path.join(HERE, "liblft_hip.so")   # LFT_LIB_PATH: experiment builds (tools/ab_build.py)
 SOURCES = ["lft_api.hip", "lft_common.cuh", "lft_kernels_a.cuh", "lft_kernels_b.cuh", "lft_train.cuh", "lft_train_host.cuh", "lft_metrics.cuh"]
+ABI_VERSION = 4                      # LFT_ABI_VERSION of include/lft_hip.h: lib() refuses a library that reports another one
+STATUS_NONFINITE = 1001              # LFT_STATUS_NONFINITE
 
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 MATH_F32, MATH_BF16X3 = 0, 1
@@ -26,12 +28,28 @@ class LftError(RuntimeError):
     pass
 
 
+def _stamp_path(lib_path: str) -> str:
+    d, _ = _objects(lib_path)
+    return os.path.join(d, os.path.basename(lib_path) + ".flags")
+
+
+def _flags_stamp() -> str:
+    """What the library was built with: the compile / link commands themselves (the per-unit flags live in this file, not
+    in a source the mtime check sees)."""
+    return "\n".join(" ".join(c) for c in build_commands("hipcc", "liblft_hip.so"))
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", "lft_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    # a change of compiler flags must rebuild too; a shipped library without a stamp (the GPU box gets the .so, not the
+    # build directory) is taken as current -- its ABI version is still checked at load time
+    stamp = _stamp_path(LIB_PATH)
+    return os.path.exists(stamp) and open(stamp).read() != _flags_stamp()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -43,6 +61,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
     compile_and_link(hipcc, LIB_PATH)
+    with open(_stamp_path(LIB_PATH), "w") as f:
+        f.write(_flags_stamp())
     return LIB_PATH
 
 
@@ -90,6 +110,8 @@ _SIGS = {
     "lft_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "lft_pack_weights": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lft_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_status_reset": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lft_status_read": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, POINTER(ctypes.c_uint)]),
     "lft_forward_profiled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                      c_int, POINTER(c_float), POINTER(c_char_p), POINTER(c_int)]),
     "lft_kernel_time": (c_int, [c_char_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, POINTER(c_float)]),
@@ -118,7 +140,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS)
 GRAD_BUCKETS = 3
-BUCKET_FN = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_size_t, c_size_t)      # lft_bucket_fn of include/lft_hip.h
+BUCKET_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_size_t, c_size_t)     # lft_bucket_fn of include/lft_hip.h: 0 = go on, else stop
 
 
 def lib() -> ctypes.CDLL:
@@ -129,6 +151,10 @@ def lib() -> ctypes.CDLL:
             raise LftError(f"{LIB_PATH} is missing: the HIP extension has not been built "
                            "(run __graft_entry__.build()); there is no CPU fallback")
         L = ctypes.CDLL(LIB_PATH)
+        L.lft_version.restype, L.lft_version.argtypes = c_int, []
+        got = L.lft_version()
+        if got != ABI_VERSION:               # a stale or foreign LFT_LIB_PATH build: its entry points may take other arguments
+            raise LftError(f"{LIB_PATH} reports ABI version {got}, this binding needs {ABI_VERSION}: rebuild it (__graft_entry__.build())")
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args

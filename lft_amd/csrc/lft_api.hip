@@ -136,7 +136,7 @@ PackedLayout packed_layout(const Dims& d, int prec) {
 }
 
 struct WorkLayout {
-    size_t x0, feat, xa, xb, tok, q, k, v, o, g, total;
+    size_t x0, feat, xa, xb, tok, q, k, v, o, g, status, total;     // status: the sticky flag word (lft_status_read), last 256 bytes
 };
 WorkLayout work_layout(const Dims& d, int prec) {
     const size_t esz = prec == LFT_PREC_F32 ? 4 : 2;
@@ -148,6 +148,7 @@ WorkLayout work_layout(const Dims& d, int prec) {
     W.tok = take(n * 128 * esz); W.q = take(n * 128 * esz); W.k = take(n * 128 * esz); W.v = take(n * 128 * esz);
     W.o = take(n * 128 * esz);
     W.g = take(n * d.gp * 4);
+    W.status = take(256);
     W.total = o;
     return W;
 }
@@ -231,7 +232,7 @@ template <typename T> bool tok_lane_major(const Dims& d) {
 // (<= 80 KiB each) or if they are the only ones fitting at all... else 8-fragment chunks (wide views, fp32).
 template <typename T, bool PE_ONLY>
 int launch_spa1(unsigned nwg, const T* in, const T* ws, const float* ln, const T* petok, T* tok, T* q, T* k, T* v, T* pe_out,
-                int nimg, const Dims& d, hipStream_t st) {
+                int nimg, const Dims& d, hipStream_t st, unsigned* status) {
     const size_t l16 = lds_spa1<T, 16>(d.w), l8 = lds_spa1<T, 8>(d.w);
     const size_t share = kMaxLds / LFT_SPA_OCC;                           // LDS per workgroup if LFT_SPA_OCC of them share a CU
     const bool use8 = (l16 > share && l8 <= share) || l16 > kMaxLds;
@@ -240,7 +241,7 @@ int launch_spa1(unsigned nwg, const T* in, const T* ws, const float* ln, const T
 #define LFT_LAUNCH_SPA1(CHV, LMV, LDSV)                                                                                     \
     do {                                                                                                                    \
         if ((rc = allow_lds(k_spa1<T, PE_ONLY, CHV, LMV>, LDSV, "k_spa1"))) return rc;                                      \
-        k_spa1<T, PE_ONLY, CHV, LMV><<<nwg, 64 * kNwSpa1, LDSV, st>>>(in, ws, ln, petok, tok, q, k, v, pe_out, nimg, d.h, d.w); \
+        k_spa1<T, PE_ONLY, CHV, LMV><<<nwg, 64 * kNwSpa1, LDSV, st>>>(in, ws, ln, petok, tok, q, k, v, pe_out, nimg, d.h, d.w, status); \
     } while (0)
     if (use8) { if (lm) LFT_LAUNCH_SPA1(8, true, l8); else LFT_LAUNCH_SPA1(8, false, l8); }
     else { if (lm) LFT_LAUNCH_SPA1(16, true, l16); else LFT_LAUNCH_SPA1(16, false, l16); }
@@ -307,7 +308,7 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
         }
         // embedded spatial position tokens of this layer (reference LFT.py:180), [h*w][128] in the activation type
         if ((rc = launch_spa1<T, true>((unsigned)((d.hw + 32 * kNwSpa1 - 1) / (32 * kNwSpa1)), at<T>(packed, L.spa_pe_img), at<T>(packed, L.s_spa1[l]), nullptr, nullptr,
-                                       nullptr, nullptr, nullptr, nullptr, at<T>(packed, L.petok[l]), 1, d, st))) return rc;
+                                       nullptr, nullptr, nullptr, nullptr, at<T>(packed, L.petok[l]), 1, d, st, nullptr))) return rc;
         LFT_LAUNCH_OK("k_spa1<pe>");
     }
     {   // up-sampler: per 32-row chunk of the 1x1 conv, followed by the matching columns of the overlap-add matrix
@@ -323,11 +324,11 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
     return 0;
 }
 
-void launch_assemble(const float* lr, const float* g, float* out, int B, int A, int h, int w, int s, hipStream_t st, int gld = 0) {
+void launch_assemble(const float* lr, const float* g, float* out, int B, int A, int h, int w, int s, hipStream_t st, int gld = 0, unsigned* status = nullptr) {
     const dim3 tg((unsigned)((A * w + 7) / 8), (unsigned)((A * h + 7) / 8), (unsigned)B);      // 8 x 8 LR mosaic pixels per workgroup
     if (!gld) gld = (s + 2) * (s + 2);
-    if (s == 2) k_assemble_t<2><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w, gld);
-    else k_assemble_t<4><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w, gld);
+    if (s == 2) k_assemble_t<2><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w, gld, status);
+    else k_assemble_t<4><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w, gld, status);
 }
 
 // ---------------------------------------------------------------------------- stages
@@ -349,7 +350,7 @@ int init_features(const void* packed, const PackedLayout& L, const float* lr, T*
     return 0;
 }
 template <typename T, int CT>
-int ang_multi(const void* packed, const PackedLayout& L, int l, const T* in, T* out, const Dims& d, hipStream_t st) {
+int ang_multi(const void* packed, const PackedLayout& L, int l, const T* in, T* out, const Dims& d, hipStream_t st, unsigned* status) {
     constexpr bool WLDS = sizeof(T) == 2;                                   // fp32 weights (128 KiB) stay in L2
     constexpr int NG = (sizeof(T) == 2 && CT <= 3) ? 2 : 1;                 // positions per workgroup (they share the LDS weights)
     constexpr size_t FB = 1024 * FragInfo<T>::PIECES;
@@ -363,7 +364,7 @@ int ang_multi(const void* packed, const PackedLayout& L, int l, const T* in, T* 
     do {                                                                                                                \
         if ((rc = allow_lds(k_ang_multi<T, CT, WLDS, NG, LL>, lds, "k_ang_multi"))) return rc;                            \
         k_ang_multi<T, CT, WLDS, NG, LL><<<grid, 64 * CT * NG, lds, st>>>(in, out, at<T>(packed, L.s_ang[l]),              \
-                                                                         at<float>(packed, L.ln_ang[l]), at<float>(packed, L.ang_pe), d.V, d.hw, npix); \
+                                                                         at<float>(packed, L.ln_ang[l]), at<float>(packed, L.ang_pe), d.V, d.hw, npix, status); \
     } while (0)
     if (rows_last <= 17) LFT_LAUNCH_ANGM(9);          // e.g. 9 x 9 = 81 views: 17 rows in the third tile
     else if (rows_last <= 25) LFT_LAUNCH_ANGM(13);
@@ -373,10 +374,10 @@ int ang_multi(const void* packed, const PackedLayout& L, int l, const T* in, T* 
     return 0;
 }
 template <typename T>
-int ang_block(const void* packed, const PackedLayout& L, int l, const T* in, T* out, const Dims& d, hipStream_t st) {
-    if (d.V > 96) return ang_multi<T, 4>(packed, L, l, in, out, d, st);
-    if (d.V > 64) return ang_multi<T, 3>(packed, L, l, in, out, d, st);      // 9x9 = 81 views
-    if (d.V > 32) return ang_multi<T, 2>(packed, L, l, in, out, d, st);
+int ang_block(const void* packed, const PackedLayout& L, int l, const T* in, T* out, const Dims& d, hipStream_t st, unsigned* status = nullptr) {
+    if (d.V > 96) return ang_multi<T, 4>(packed, L, l, in, out, d, st, status);
+    if (d.V > 64) return ang_multi<T, 3>(packed, L, l, in, out, d, st, status);      // 9x9 = 81 views
+    if (d.V > 32) return ang_multi<T, 2>(packed, L, l, in, out, d, st, status);
     const int npix = d.B * d.hw;
     const size_t lds = lds_ang<T>();
     int rc;
@@ -384,11 +385,11 @@ int ang_block(const void* packed, const PackedLayout& L, int l, const T* in, T* 
     if (d.V <= 25) {                                                  // 5 x 5 and smaller: score rows 25..31 are never a view
         if ((rc = allow_lds(k_ang<T, 13>, lds, "k_ang"))) return rc;
         k_ang<T, 13><<<grid, 256, lds, st>>>(in, out, at<T>(packed, L.s_ang[l]), at<float>(packed, L.ln_ang[l]),
-                                             at<float>(packed, L.ang_pe), d.V, d.hw, npix);
+                                             at<float>(packed, L.ang_pe), d.V, d.hw, npix, status);
     } else {
         if ((rc = allow_lds(k_ang<T, 16>, lds, "k_ang"))) return rc;
         k_ang<T, 16><<<grid, 256, lds, st>>>(in, out, at<T>(packed, L.s_ang[l]), at<float>(packed, L.ln_ang[l]),
-                                             at<float>(packed, L.ang_pe), d.V, d.hw, npix);
+                                             at<float>(packed, L.ang_pe), d.V, d.hw, npix, status);
     }
     LFT_LAUNCH_OK("k_ang");
     return 0;
@@ -399,7 +400,7 @@ int spa_part_a(const void* packed, const PackedLayout& L, int l, const T* in, vo
     const int nimg = d.B * d.V, nwg = nimg * ((d.hw + 32 * kNwSpa1 - 1) / (32 * kNwSpa1));
     int rc;
     if ((rc = launch_spa1<T, false>((unsigned)nwg, in, at<T>(packed, L.s_spa1[l]), at<float>(packed, L.ln_spa[l]), at<T>(packed, L.petok[l]),
-                                    at<T>(ws, W.tok), at<T>(ws, W.q), at<T>(ws, W.k), at<T>(ws, W.v), nullptr, nimg, d, st))) return rc;
+                                    at<T>(ws, W.tok), at<T>(ws, W.q), at<T>(ws, W.k), at<T>(ws, W.v), nullptr, nimg, d, st, at<unsigned>(ws, W.status)))) return rc;
     LFT_LAUNCH_OK("k_spa1");
     return 0;
 }
@@ -417,7 +418,7 @@ int spa_part_b(const void* packed, const PackedLayout& L, int l, const T* skip, 
 #define LFT_LAUNCH_SPAB(SKV, LMV, YLV)                                                                                      \
     do {                                                                                                                    \
         if ((rc = allow_lds(k_spa_b<T, SKV, LMV, YLV>, lds, "k_spa_b"))) return rc;                                            \
-        k_spa_b<T, SKV, LMV, YLV><<<ntile, 256, lds, st>>>(tok, q, k, v, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.h, d.w); \
+        k_spa_b<T, SKV, LMV, YLV><<<ntile, 256, lds, st>>>(tok, q, k, v, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.h, d.w, at<unsigned>(ws, W.status)); \
     } while (0)
         const bool tlm = tok_lane_major<T>(d);
         if (out_lm && !(skip && tlm)) return fail(LFT_ERR_ARG, "internal: lane-major output needs the skip variant and lane-major tokens");
@@ -439,7 +440,7 @@ int spa_part_b(const void* packed, const PackedLayout& L, int l, const T* skip, 
 #define LFT_LAUNCH_SPA2(SKV, LMV, YLV)                                                                                      \
     do {                                                                                                                    \
         if ((rc = allow_lds(k_spa2<T, SKV, LMV, YLV>, lds_spa2<T>(), "k_spa2"))) return rc;                                 \
-        k_spa2<T, SKV, LMV, YLV><<<nb, 64 * kNwSpa2, lds_spa2<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.ntok); \
+        k_spa2<T, SKV, LMV, YLV><<<nb, 64 * kNwSpa2, lds_spa2<T>(), st>>>(tok, o, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.ntok, at<unsigned>(ws, W.status)); \
     } while (0)
     if (out_lm && !(skip && lm)) return fail(LFT_ERR_ARG, "internal: lane-major output needs the skip variant and full tiles");
     if (skip) { if (out_lm) LFT_LAUNCH_SPA2(true, true, true); else if (lm) LFT_LAUNCH_SPA2(true, true, false); else LFT_LAUNCH_SPA2(true, false, false); }
@@ -471,7 +472,7 @@ int upsample(const void* packed, const PackedLayout& L, const T* body, const flo
     else { if (in_lm) LFT_LAUNCH_UP(2, true); else LFT_LAUNCH_UP(2, false); }
 #undef LFT_LAUNCH_UP
     LFT_LAUNCH_OK("k_up");
-    launch_assemble(lr, g, out, d.B, d.A, d.h, d.w, d.s, st);
+    launch_assemble(lr, g, out, d.B, d.A, d.h, d.w, d.s, st, 0, at<unsigned>(ws, W.status));
     LFT_LAUNCH_OK("k_assemble");
     return 0;
 }
@@ -485,7 +486,7 @@ int forward_impl(const void* packed, const float* lr, float* out, void* ws, cons
     if ((rc = init_features<T>(packed, L, lr, x0, xa, xb, feat, d, st))) return rc;
     const T* cur = feat;
     for (int l = 0; l < kLayers; ++l) {                  // angular first, then spatial (reference LFT.py:249-250)
-        if ((rc = ang_block<T>(packed, L, l, cur, xa, d, st))) return rc;
+        if ((rc = ang_block<T>(packed, L, l, cur, xa, d, st, at<unsigned>(ws, W.status)))) return rc;
         const bool last = l == kLayers - 1;                  // its output only feeds the up-sampler: same 32-token tiling, lane-major tiles
         if ((rc = spa_block<T>(packed, L, l, xa, last ? feat : nullptr, xb, ws, W, d, st, last && LFT_YLM && tok_lane_major<T>(d)))) return rc;
         cur = xb;
@@ -503,7 +504,7 @@ int kernel_time_impl(const char* name, const void* packed, void* ws, const Dims&
     T *x0 = at<T>(ws, W.x0), *feat = at<T>(ws, W.feat), *xa = at<T>(ws, W.xa), *xb = at<T>(ws, W.xb);
     const std::string k(name);
     auto once = [&]() -> int {
-        if (k == "k_ang") return ang_block<T>(packed, L, 1, xb, xa, d, st);
+        if (k == "k_ang") return ang_block<T>(packed, L, 1, xb, xa, d, st, at<unsigned>(ws, W.status));
         if (k == "k_spa1") return spa_part_a<T>(packed, L, 1, xa, ws, W, d, st);
         if (k == "k_spa_b" || k == "k_spa_attn+k_spa2") return spa_part_b<T>(packed, L, 1, nullptr, xb, ws, W, d, st);
         if (k == "k_conv64") {
@@ -576,6 +577,28 @@ int lft_forward(const void* packed, const float* lr, float* out, void* workspace
     if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     return LFT_BY_PREC(prec, forward_impl<T>(packed, lr, out, workspace, d, prec, st));
+}
+
+int lft_status_reset(void* workspace, int B, int A, int h, int w, int s, int prec, void* stream) {
+    Dims d; int rc;
+    if (!workspace) return fail(LFT_ERR_ARG, "null pointer");
+    if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
+    LFT_HIP_OK(hipMemsetAsync(at<char>(workspace, work_layout(d, prec).status), 0, 256, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+int lft_status_read(const void* workspace, int B, int A, int h, int w, int s, int prec, void* stream, unsigned* host_flags) {
+    Dims d; int rc;
+    if (!workspace) return fail(LFT_ERR_ARG, "null pointer");
+    if ((rc = make_dims(B, A, h, w, s, prec, &d))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned flags = 0;
+    LFT_HIP_OK(hipMemcpyAsync(&flags, at<char>(workspace, work_layout(d, prec).status), sizeof(flags), hipMemcpyDeviceToHost, st));
+    LFT_HIP_OK(hipStreamSynchronize(st));
+    if (host_flags) *host_flags = flags;
+    if (flags == 0) return 0;
+    return fail(LFT_STATUS_NONFINITE, "non-finite activations or outputs since the last lft_status_reset (flags 0x%x)%s", flags,
+                prec == LFT_PREC_F16 ? ": an activation left the fp16 range (|x| > 65504) or the input holds inf / NaN -- use LFT_PREC_BF16 or LFT_PREC_F32 for these weights"
+                                     : ": the input or the weights hold inf / NaN, or an activation overflowed");
 }
 
 int lft_forward_profiled(const void* packed, const float* lr, float* out, void* workspace, int B, int A, int h, int w, int s, int prec,
@@ -692,8 +715,8 @@ int lft_debug_conv64(const void* packed, int which, int with_res, const void* in
     return 0;
 }
 
-#ifdef LFT_STAMPS
-// Diagnostic build only: copy the stamp buffer to the host (synchronises).
+#ifdef LFT_EXPERIMENT
+// Diagnostic build only (lft_experiment.cuh): copy the stamp buffer to the host (synchronises).
 int lft_debug_read_stamps(unsigned long long* host_out, int n) {
     LFT_HIP_OK(hipDeviceSynchronize());
     LFT_HIP_OK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_lft_stamps), sizeof(unsigned long long) * (size_t)n));

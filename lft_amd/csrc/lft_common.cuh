@@ -59,18 +59,11 @@ typedef unsigned int raw16 __attribute__((ext_vector_type(4), may_alias));
 #define LFT_DEV static __device__ __forceinline__
 #define LFT_MEM __device__ __forceinline__
 
-// Diagnostic build only (-DLFT_STAMPS): per-phase s_memtime stamps of wave 0 of every workgroup go to a
-// side buffer that no kernel reads (tools/stamp_report.py).  In the product build LFT_STAMP() is empty.
-#ifdef LFT_STAMPS
-__device__ unsigned long long g_lft_stamps[4096 * 32];    // 32 slots per workgroup: k_spa1 uses 0..15, k_spa2 16..31
-LFT_DEV void lft_stamp(int slot) {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (threadIdx.x == 0 && blockIdx.x < 4096) g_lft_stamps[blockIdx.x * 32 + slot] = t;
-}
-#define LFT_STAMP(slot) lft_stamp(slot)
+// In-kernel phase stamps (LFT_STAMP) and other timing experiments live in lft_experiment.cuh, which only a diagnostic
+// build includes (-DLFT_EXPERIMENT, tools/stamp_report.py); in the product build LFT_STAMP() is empty and nothing else of
+// that header exists.
+#ifdef LFT_EXPERIMENT
+#include "lft_experiment.cuh"
 #else
 #define LFT_STAMP(slot) ((void)0)
 #endif
@@ -253,9 +246,6 @@ struct WRing {
     // Every wave issues exactly PIECES_PER_WAVE DMA instructions per chunk (clamped to the last piece of the
     // stream when the chunk is short) so that the counted wait below is exact.
     LFT_MEM void issue(int c) {
-#ifdef LFT_EXP_NO_RING_DMA
-        if (c >= NBUF) return;                                         // experiment: the first fill only
-#endif
         if (c * CH >= nfrag) return;                                   // uniform: chunk does not exist
         const char* src = g + (size_t)c * CHUNK_BYTES;
         char* dst = lds + (c % NBUF) * CHUNK_BYTES;
@@ -311,9 +301,6 @@ struct WRingDeep {
         return lds + s * CHUNK_BYTES + (s >= split_slot ? split_gap : 0);
     }
     LFT_MEM void issue(int c) {                                         // every wave issues exactly PIECES_PER_WAVE pieces per existing chunk
-#ifdef LFT_EXP_NO_RING_DMA
-        if (c >= NBUF) return;
-#endif
         if (c * CH >= nfrag) return;
         const char* src = g + (size_t)c * CHUNK_BYTES;
         char* dst = slot(c);
@@ -456,11 +443,7 @@ LFT_DEV int store_tile_lm(T* __restrict__ tile_base, int lane, const f32x16 (&a)
                 typename H16<T>::v8 v;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (T)a[nt][8 * k + j];
-#ifndef LFT_EXP_NO_TILE_STORES
                 store_raw16(reinterpret_cast<char*>(dst), __builtin_bit_cast(raw16, v));
-#else
-                asm volatile("" :: "v"(v), "v"(dst));
-#endif
             } else {
                 store_raw16(reinterpret_cast<char*>(dst), __builtin_bit_cast(raw16, f32x4{a[nt][8 * k], a[nt][8 * k + 1], a[nt][8 * k + 2], a[nt][8 * k + 3]}));
                 store_raw16(reinterpret_cast<char*>(dst + 4), __builtin_bit_cast(raw16, f32x4{a[nt][8 * k + 4], a[nt][8 * k + 5], a[nt][8 * k + 6], a[nt][8 * k + 7]}));
@@ -578,11 +561,7 @@ LFT_DEV int store_tile(T* __restrict__ gbase, int nvalid, int lane, const f32x16
 #pragma unroll
         for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
             const int idx = i * 64 + lane, row = idx / IO::P16, pc = idx % IO::P16;
-#ifndef LFT_EXP_NO_TILE_STORES           // experiment build only (tools/ab_build.py): results are wrong on purpose
             if (pass * 16 + row < nvalid) store_raw16(g0 + (size_t)row * STRIDE + pc * 16, v[i]);
-#else
-            asm volatile("" :: "v"(v[i]));
-#endif
         }
     }
     return 2 * (16 * IO::P16 / 64);
@@ -698,11 +677,7 @@ LFT_DEV void store_tile_map(T* __restrict__ gbase, const RM& rm, int lane, const
 #pragma unroll
         for (int i = 0; i < 16 * IO::P16 / 64; ++i) {
             const int idx = i * 64 + lane, row = pass * 16 + idx / IO::P16, pc = idx % IO::P16;
-#ifndef LFT_EXP_NO_TILE_STORES
             if (rm.ok(row)) store_raw16(reinterpret_cast<char*>(gbase) + rm.off(row) + pc * 16, v[i]);
-#else
-            asm volatile("" :: "v"(v[i]));
-#endif
         }
     }
 }
@@ -814,8 +789,13 @@ LFT_DEV float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
 // FAST (bf16 path): v_rsq_f32 / v_rcp_f32 (1 ulp) instead of sqrt + IEEE division (a dozen instructions per token; the
 // kernels that call this are bound by vector-instruction issue).  The fp32 parity path keeps the exact forms.
 LFT_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// `bad` (sticky, per lane): set when the token's variance is not finite, i.e. some channel of the token is inf / NaN.  Every
+// activation of the residual stream passes through one of these LayerNorms in the following block, and an fp16 range
+// overflow anywhere upstream (a finite fp32 value converted to +-inf) turns into inf / NaN there: one compare per token is
+// the network's overflow detector (lft_status_read; the last block's output is checked by k_assemble_t).
+LFT_DEV unsigned not_finite(float v) { return !(__builtin_fabsf(v) < 3.0e38f); }
 template <int NT, bool FAST = false>
-LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* gamma, const float* beta, int h) {
+LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* gamma, const float* beta, int h, unsigned& bad) {
     if constexpr (FAST) {
         // 16-bit paths: every pass on register pairs (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32), the centred value kept
         // from the variance pass, gamma folded into the scale: 2.5 vector instructions per element instead of 6 -- these
@@ -837,7 +817,9 @@ LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* gamma, const float* bet
                 q2 = p2_fma(d, d, q2);
                 a[nt][i] = d[0]; a[nt][i + 1] = d[1];
             }
-        const float rstd = __builtin_amdgcn_rsqf(xhalf_sum(q2[0] + q2[1]) * (1.0f / (NT * 32)) + LFT_LN_EPS);
+        const float var = xhalf_sum(q2[0] + q2[1]) * (1.0f / (NT * 32)) + LFT_LN_EPS;
+        bad |= not_finite(var);
+        const float rstd = __builtin_amdgcn_rsqf(var);
         const f32x2 rstd2 = {rstd, rstd};
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -866,6 +848,7 @@ LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* gamma, const float* bet
 #pragma unroll
         for (int i = 0; i < 16; ++i) { float d = a[nt][i] - mean; q += d * d; }
     const float var = xhalf_sum(q) * (1.0f / (NT * 32)) + LFT_LN_EPS;
+    bad |= not_finite(var);
     const float rstd = FAST ? __builtin_amdgcn_rsqf(var) : 1.0f / sqrtf(var);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -876,6 +859,12 @@ LFT_DEV void layernorm_acc(f32x16 (&a)[NT], const float* gamma, const float* bet
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[nt][4 * g + j] = (a[nt][4 * g + j] - mean) * rstd * gm[j] + bt[j];
         }
+}
+// Publish a kernel's sticky "non-finite activation seen" bit (status may be null: per-stage entry points without a workspace).
+// Many lanes may store the same word; the value only ever goes from 0 to non-zero until lft_status_reset.
+constexpr unsigned LFT_STATUS_NONFINITE_BIT = 1u;
+LFT_DEV void publish_status(unsigned* status, unsigned bad) {
+    if (bad && status) *status = LFT_STATUS_NONFINITE_BIT;
 }
 // LayerNorm parameters global -> LDS in two halves: the load is issued early with everything else, the LDS
 // store only after the kernel's one big vmcnt wait (a load -> ds_write pair in the prologue costs a full memory

@@ -308,11 +308,12 @@ LFT_DEV void linear_lds(const char* wl, int f0, int lane, const Frag<T> (&x)[KS]
 template <typename T, int NLIVE = 16>
 __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ ws,
                                              const float* __restrict__ ln, const float* __restrict__ pe,
-                                             int V, int hw, int npix) {
+                                             int V, int hw, int npix, unsigned* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int FB = 1024 * FragInfo<T>::PIECES;
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned bad = 0;                                                  // non-finite activation seen (layernorm_acc)
     {
         const char* g = reinterpret_cast<const char*>(ws);
 #pragma unroll
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
             for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
             add_acc_raw<2, float>(n, pr, ok);
         }
-        layernorm_acc<2, sizeof(T) == 2>(n, lds_ln, lds_ln + 64, hh);
+        layernorm_acc<2, sizeof(T) == 2>(n, lds_ln, lds_ln + 64, hh, bad);
         Frag<T> nf[4], xf[4];
         acc_frags<2, T>(n, nf);
         acc_frags<2, T>(x, xf);
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
         linear_lds<2, 4, T>(smem, 24, lane, of, x);              // t = x + O Wo^T
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
-        layernorm_acc<2, sizeof(T) == 2>(n, lds_ln + 128, lds_ln + 192, hh);
+        layernorm_acc<2, sizeof(T) == 2>(n, lds_ln + 128, lds_ln + 192, hh, bad);
         acc_frags<2, T>(n, nf);
         f32x16 hid[4];
         zero_acc<4>(hid);
@@ -424,6 +425,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
         LFT_STAMP(6 + 5 * stamp_it);
         stamp_it = 1;
     }
+    publish_status(status, bad);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -441,10 +443,11 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
 template <typename T, int CT, bool WLDS, int NG, int LASTLIVE = 16>
 __global__ __launch_bounds__(64 * CT * NG) void k_ang_multi(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ ws,
                                                             const float* __restrict__ ln, const float* __restrict__ pe,
-                                                            int V, int hw, int npix) {
+                                                            int V, int hw, int npix, unsigned* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int FB = 1024 * FragInfo<T>::PIECES;
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    unsigned bad = 0;                                                  // non-finite activation seen (layernorm_acc)
     const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave_all / CT, wave = wave_all % CT;             // position group, column tile inside the position
     char* lds_w = smem;                                            // 64 weight fragments when WLDS
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(64 * CT * NG) void k_ang_multi(const T* __restrict_
             for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
             add_acc_raw<2, float>(n, pr, ok);
         }
-        layernorm_acc<2, sizeof(T) == 2>(n, lds_ln, lds_ln + 64, hh);
+        layernorm_acc<2, sizeof(T) == 2>(n, lds_ln, lds_ln + 64, hh, bad);
         Frag<T> nf[4], xf[4];
         acc_frags<2, T>(n, nf);
         acc_frags<2, T>(x, xf);
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(64 * CT * NG) void k_ang_multi(const T* __restrict_
             for (int ks = 0; ks < 4; ++ks) mma(wfrag(24 + nt * 4 + ks), of[ks], x[nt]);         // t = x + O Wo^T
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) n[nt] = x[nt];
-        layernorm_acc<2>(n, lds_ln + 128, lds_ln + 192, hh);
+        layernorm_acc<2>(n, lds_ln + 128, lds_ln + 192, hh, bad);
         acc_frags<2, T>(n, nf);
         f32x16 hid[4];
         zero_acc<4>(hid);
@@ -602,4 +605,5 @@ __global__ __launch_bounds__(64 * CT * NG) void k_ang_multi(const T* __restrict_
         if constexpr (sizeof(T) == 2) store_tile<2, T>(Y + off, active ? nrows : 0, lane, x, scr, vstride);
         else store_acc<2, T>(Y + (((size_t)b * V + min(view, V - 1)) * hw + p) * 64, ok && active, hh, x);
     }
+    publish_status(status, bad);
 }

@@ -39,7 +39,7 @@ template <typename T, bool PE_ONLY, int CH = kSpaChunk, bool TOKLM = false, int 
 __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const T* __restrict__ petok,
                                               T* __restrict__ TOK, T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vv,
-                                              T* __restrict__ pe_out, int nimg, int h, int w) {
+                                              T* __restrict__ pe_out, int nimg, int h, int w, unsigned* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5, wave = threadIdx.x >> 6;
     constexpr int TT = 32 * NW;                                       // tokens per workgroup tile
@@ -103,7 +103,8 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
     }
     LFT_STAMP(6);
     add_acc_raw<4, T>(t, pe_raw, ok);
-    layernorm_acc<4, sizeof(T) == 2>(t, lds_ln, lds_ln + 128, hh);
+    unsigned bad = 0;
+    layernorm_acc<4, sizeof(T) == 2>(t, lds_ln, lds_ln + 128, hh, bad);        // also the overflow detector for the token embedding
     acc_frags<4, T>(t, nf);
     LFT_STAMP(7);
 #pragma unroll
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
         else store_tile<2, T, 128>(K + tile_off + 64 * half, nvalid, lane, a, scr);
     }
     LFT_STAMP(11);
+    publish_status(status, bad);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -148,7 +150,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <typename T, bool SKIP, bool TOKLM = false, bool YLM = false, int NW = kNwSpa2>   // YLM: output tile in lane-major form (consumer: k_up)
 __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa2(const T* __restrict__ TOK, const T* __restrict__ O, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const T* __restrict__ skip, T* __restrict__ Y,
-                                              long long ntok) {
+                                              long long ntok, unsigned* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int wave = threadIdx.x >> 6;
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa2(const T* __restri
     LFT_STAMP(18);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] = t[nt];
-    layernorm_acc<4>(n, lds_ln, lds_ln + 128, hh);
+    unsigned bad = 0;
+    layernorm_acc<4>(n, lds_ln, lds_ln + 128, hh, bad);
     acc_frags<4, T>(n, f);
     LFT_STAMP(19);
 #pragma unroll
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa2(const T* __restri
     if constexpr (YLM) store_tile_lm<2, T>(Y + tb * 64, lane, y);
     else store_tile<2, T>(Y + tb * 64, nvalid, lane, y, scr);
     LFT_STAMP(22);
+    publish_status(status, bad);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -250,7 +254,7 @@ template <int N> LFT_DEV void wait_vm_q(raw16& a, raw16& b) {          // s_wait
 template <typename T, bool SKIP, bool TOKLM = false, bool YLM = false>   // TOKLM: k_spa1 wrote the tokens as lane-major 32-token tiles (w % 32 == 0: a tile = 32 columns of one image row); YLM: write the output so (consumer: k_up)
 __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, const T* __restrict__ Q, const T* __restrict__ K,
                                                   const T* __restrict__ Vv, const T* __restrict__ ws, const float* __restrict__ ln,
-                                                  const T* __restrict__ skip, T* __restrict__ Y, int h, int w) {
+                                                  const T* __restrict__ skip, T* __restrict__ Y, int h, int w, unsigned* __restrict__ status) {
     static_assert(sizeof(T) == 2, "k_spa_b is the 16-bit (bf16 / f16) part B; fp32 uses k_win_attn_lds + k_spa2");
     typedef typename H16<T>::v8 V8;
     using Ring = WRingDeep<T, kSpaBChunk, 4, kSpaBSlots>;
@@ -467,7 +471,8 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
     LFT_STAMP(27);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] = t[nt];
-    layernorm_acc<4, true>(n, lds_ln, lds_ln + 128, hh);
+    unsigned bad = 0;
+    layernorm_acc<4, true>(n, lds_ln, lds_ln + 128, hh, bad);                  // t carries whatever overflowed in tok / Q / K / V / the attention
     Frag<T> f[8];
     acc_frags<4, T>(n, f);
 #pragma unroll
@@ -511,6 +516,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
         store_tile_map<2, T>(Y + tok0 * 64, ry, lane, y, scr);
     }
     LFT_STAMP(30);
+    publish_status(status, bad);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(256) void k_bicubic(const float* __restrict__ lr, f
 // (S+2)^2 = 36 or 16 floats).  The bicubic taps come from the LR mosaic, which is cache-resident (0.1 MB per patch).
 template <int S>
 __global__ __launch_bounds__(256) void k_assemble_t(const float* __restrict__ lr, const float* __restrict__ G, float* __restrict__ out,
-                                                    int B, int A, int h, int w, int gld) {      // gld: floats between the footprints of consecutive tokens (>= GP)
+                                                    int B, int A, int h, int w, int gld, unsigned* __restrict__ status) {      // gld: floats between the footprints of consecutive tokens (>= GP)
     constexpr int TL = 8, HL = TL + 2, GP = (S + 2) * (S + 2), P4 = GP / 4, TS = TL * S;
     __shared__ __attribute__((aligned(16))) float gs[HL * HL * GP];
     const int MH = A * h, MW = A * w, HR_W = MW * S, HR_H = MH * S;
@@ -632,6 +638,7 @@ __global__ __launch_bounds__(256) void k_assemble_t(const float* __restrict__ lr
         *reinterpret_cast<f32x4*>(gs + slot * GP + part * 4) = v;
     }
     __syncthreads();
+    unsigned bad = 0;                                                  // the network's output is the last place an overflow can show
     for (int idx = threadIdx.x; idx < TS * TS; idx += 256) {
         const int Yl = idx / TS, Xl = idx - Yl * TS;
         const int Y = by0 * S + Yl, X = bx0 * S + Xl;
@@ -651,8 +658,10 @@ __global__ __launch_bounds__(256) void k_assemble_t(const float* __restrict__ lr
                 v += gs[((ql + dy) * HL + qc + dx) * GP + (I + 1) * (S + 2) + (J + 1)];
             }
         }
+        bad |= not_finite(v);
         out[((size_t)b * HR_H + Y) * HR_W + X] = v;
     }
+    publish_status(status, bad);
 }
 
 // ------------------------------------------------------------------------------------------

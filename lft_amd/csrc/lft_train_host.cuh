@@ -439,7 +439,7 @@ void grad_bucket_range(int s, int bucket, size_t* first, size_t* count) {
     else if (bucket == 1) { *first = cut0; *count = cut1 - cut0; }      // altblock.0, altblock.1
     else { *first = 0; *count = cut0; }                                  // conv_init0, conv_init
 }
-typedef void (*BucketFn)(void* user, int bucket, size_t first_float, size_t n_floats);
+typedef int (*BucketFn)(void* user, int bucket, size_t first_float, size_t n_floats);
 
 int train_backward(const float* const* P, const float* lr, float* tape, const float* dout, float* G, const Dims& d, int math,
                    hipStream_t st, hipStream_t side, BucketFn on_bucket = nullptr, void* user = nullptr) {
@@ -486,7 +486,8 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
         if (on_bucket) {
             size_t first, count;
             grad_bucket_range(d.s, bucket, &first, &count);
-            on_bucket(user, bucket, first, count);
+            if (on_bucket(user, bucket, first, count) != 0)              // the caller asked to stop: enqueue nothing further
+                return fail(LFT_ERR_CALLBACK, "on_bucket asked to stop at bucket %d", bucket);
         }
         return 0;
     };

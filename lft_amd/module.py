@@ -72,6 +72,10 @@ class get_model(nn.Module):
             self._names.append(name)
         # GEMM arithmetic of the training kernels: 'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16, ~1e-5 relative)
         self.train_math = getattr(args, "lft_train_math", "fp32")
+        # After every eager forward, read the workspaces' status word and raise on non-finite activations (an fp16 range
+        # overflow).  Costs a device synchronisation per call, so it is on by default only where the risk is (fp16);
+        # captured graphs / pipelines never check by themselves: call check_status() (GraphedForward.check / PipelinedForward.sync).
+        self.check_finite = bool(getattr(args, "lft_check_finite", self.precision in ("fp16", "f16", "float16")))
         self._packed = None        # (key, tensor)
         self._work = {}            # slot -> (key, tensor)
         self._side_streams = {}    # device -> [torch.cuda.Stream]
@@ -107,7 +111,32 @@ class get_model(nn.Module):
             nbytes = _lib.workspace_bytes(B, self.angRes, h, w, self.factor, prec)
             cur = (key, torch.empty(nbytes, dtype=torch.uint8, device=dev))
             self._work[slot] = cur
+            # the workspace's sticky status word starts clear (ordered on the current stream, like every later use)
+            _lib.check(_lib.lib().lft_status_reset(cur[1].data_ptr(), B, self.angRes, h, w, self.factor, prec,
+                                                   torch.cuda.current_stream(dev).cuda_stream), "lft_status_reset")
         return cur[1]
+
+    def check_status(self, reset: bool = True) -> None:
+        """Raise LftError if any forward since the last check saw a non-finite activation or output -- on the fp16 path: an
+        activation left the half-precision range (|x| > 65504), which must be a loud error, never a silently wrong image.
+        Reads the sticky status word of every workspace this module owns (eager forwards, captured graphs, pipelines);
+        synchronises the device."""
+        bad = []
+        for slot, (key, buf) in self._work.items():
+            _, B, h, w, prec = key
+            with torch.cuda.device(buf.device):
+                stream = torch.cuda.current_stream(buf.device).cuda_stream
+                torch.cuda.synchronize(buf.device)              # forwards on side / pipeline streams included
+                flags = ctypes.c_uint(0)
+                rc = _lib.lib().lft_status_read(buf.data_ptr(), B, self.angRes, h, w, self.factor, prec, stream, ctypes.byref(flags))
+                if rc == _lib.STATUS_NONFINITE:
+                    bad.append((slot, _lib.lib().lft_last_error().decode()))
+                    if reset:
+                        _lib.check(_lib.lib().lft_status_reset(buf.data_ptr(), B, self.angRes, h, w, self.factor, prec, stream), "lft_status_reset")
+                else:
+                    _lib.check(rc, "lft_status_read")
+        if bad:
+            raise _lib.LftError(f"{self.precision} forward: {bad[0][1]} (workspace slots {[b[0] for b in bad]})")
 
     # ------------------------------------------------------------------ forward
     def forward(self, lr: torch.Tensor, _slot_base: int = 0) -> torch.Tensor:
@@ -145,17 +174,19 @@ class get_model(nn.Module):
                 side = self._side_streams.setdefault(x.device, [])
                 while len(side) < nsplit:
                     side.append(torch.cuda.Stream(device=x.device))
-                ready = torch.cuda.Event()
-                ready.record(main)                      # inputs, packed weights and `out` are ordered on the caller's stream
                 from .dp import shard_range
-                for i in range(nsplit):
-                    b0, b1 = shard_range(B, i, nsplit)
+                shards = [shard_range(B, i, nsplit) for i in range(nsplit)]
+                works = [self._ensure_work(x.device, b1 - b0, h, w, prec, slot=(_slot_base, i)) for i, (b0, b1) in enumerate(shards)]
+                ready = torch.cuda.Event()
+                ready.record(main)                      # inputs, packed weights, `out` and fresh workspaces are ordered on the caller's stream
+                for i, (b0, b1) in enumerate(shards):
                     st = side[i]
                     st.wait_event(ready)
-                    work = self._ensure_work(x.device, b1 - b0, h, w, prec, slot=(_slot_base, i))
-                    _lib.check(_lib.lib().lft_forward(packed.data_ptr(), x[b0:b1].data_ptr(), out[b0:b1].data_ptr(), work.data_ptr(),
+                    _lib.check(_lib.lib().lft_forward(packed.data_ptr(), x[b0:b1].data_ptr(), out[b0:b1].data_ptr(), works[i].data_ptr(),
                                                       b1 - b0, A, h, w, s, prec, st.cuda_stream), "lft_forward")
                     main.wait_stream(st)                # the caller's stream sees the finished sub-batch
+            if self.check_finite and not torch.cuda.is_current_stream_capturing():
+                self.check_status()                     # fp16 by default: an overflow raises here (synchronises, like the .cpu() that follows in test.py)
         return out
 
 
@@ -179,16 +210,32 @@ class GraphedForward:
             with torch.cuda.graph(self.graph):
                 self.static_out = net(self.static_in, _slot_base=slot_base)
             # The graph has the packed-weight buffer's address baked in: keep the buffer alive, and refuse to replay once
-            # the module has dropped or replaced it (optimizer step, load_state_dict, checkpoint load) -- a replay would
-            # read freed memory, not merely stale weights.
+            # the module has dropped or replaced it, or once any parameter has changed since it was packed (optimizer step,
+            # load_state_dict, in-place edits: they bump the tensors' version counters without touching net._packed) -- a
+            # replay would read freed memory or silently use the old weights.
             self._packed = net._packed
+            self._params = net._params_in_order()     # the Parameter objects whose (data_ptr, version) the pack key records
+
+    def check_fresh(self) -> None:
+        """Raise unless the captured packed-weight buffer still is the module's and still matches its parameters
+        (78 data_ptr / version reads on the host, ~15 us)."""
+        net = self.net
+        if net._packed is not self._packed:
+            raise RuntimeError("the model's weights were re-packed or dropped since this graph was captured "
+                               "(optimizer step / load_state_dict): create a new GraphedForward")
+        key = self._packed[0]
+        if net._pack_key(self._params, key[0], key[1], key[2]) != key:
+            raise RuntimeError("the model's parameters changed since this graph was captured (load_state_dict / optimizer "
+                               "step / in-place update): create a new GraphedForward")
+
+    def check(self) -> None:
+        """Overflow / non-finite check of every replay so far (module.check_status: synchronises, raises LftError)."""
+        self.net.check_status()
 
     def __call__(self, lr: torch.Tensor) -> torch.Tensor:
         if lr.shape != self.static_in.shape:
             raise ValueError(f"graph was captured for {tuple(self.static_in.shape)}, got {tuple(lr.shape)}")
-        if self.net._packed is not self._packed:
-            raise RuntimeError("the model's weights were re-packed or dropped since this graph was captured "
-                               "(optimizer step / load_state_dict): create a new GraphedForward")
+        self.check_fresh()
         if lr.data_ptr() != self.static_in.data_ptr():
             self.static_in.copy_(lr)
         self.graph.replay()
@@ -214,8 +261,7 @@ class PipelinedForward:
         k = self.i % self.depth
         self.i += 1
         g, st = self.graphs[k], self.streams[k]
-        if g.net._packed is not g._packed:
-            raise RuntimeError("the model's weights were re-packed or dropped since this pipeline was captured: create a new PipelinedForward")
+        g.check_fresh()                                                      # weights re-packed, dropped or changed in place: refuse
         st.wait_stream(torch.cuda.current_stream(g.static_in.device))       # the caller's input is ready
         with torch.cuda.stream(st):
             if lr is not None and lr.data_ptr() != g.static_in.data_ptr():
@@ -225,10 +271,14 @@ class PipelinedForward:
         self.event = self.events[k]
         return g.static_out
 
-    def sync(self) -> None:
+    def sync(self, check: bool = False) -> None:
+        """Order the caller's stream after every step in flight.  check=True additionally reads the status words (device
+        synchronisation) and raises LftError if any replay saw a non-finite activation (fp16 overflow)."""
         cur = torch.cuda.current_stream(self.graphs[0].static_in.device)
         for st in self.streams:
             cur.wait_stream(st)
+        if check:
+            self.graphs[0].net.check_status()
 
 
 class get_loss(nn.Module):

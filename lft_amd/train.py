@@ -107,7 +107,8 @@ def grad_bucket(s: int, bucket: int):
 def train_backward_buckets(ps, lr, tape, dout, A, s, grads, on_bucket, math="fp32", overlap=True):
     """lft_train_backward_buckets: the backward pass, calling on_bucket(bucket, first_float, n_floats) on the host each
     time a contiguous range of the flat gradient buffer is final (its last kernel enqueued on the current stream).
-    An exception raised by on_bucket is re-raised here after the call returns."""
+    An exception raised by on_bucket stops the pass at that boundary (the C call enqueues nothing further and returns
+    LFT_ERR_CALLBACK) and is re-raised here."""
     B, _, H, W = lr.shape
     h, w = H // A, W // A
     dev = lr.device
@@ -115,12 +116,12 @@ def train_backward_buckets(ps, lr, tape, dout, A, s, grads, on_bucket, math="fp3
     err = []
 
     def trampoline(_user, bucket, first, count):
-        if err:
-            return
         try:
             on_bucket(int(bucket), int(first), int(count))
+            return 0
         except BaseException as e:          # noqa: BLE001 -- must not propagate through the C frame
             err.append(e)
+            return 1                        # tells lft_train_backward_buckets to stop: nothing further is enqueued
 
     cb = _lib.BUCKET_FN(trampoline)
     rc = _lib.lib().lft_train_backward_buckets(_ptr_array(ps), len(ps), lr.data_ptr(), tape.data_ptr(), dout.data_ptr(), grads.data_ptr(),
@@ -179,6 +180,7 @@ class TrainStep:
         self.use_graph = bool(graph)
         self._graphs = {}
         self.group = process_group
+        self.exchange = True               # False: skip the gradient exchange although a process group exists (bench.py times the step both ways)
         ps = net._params_in_order()
         dev = ps[0].device
         _check_params(ps, dev)
@@ -257,12 +259,19 @@ class TrainStep:
                     graphs[0].capture_begin()
                     try:
                         g["out"] = self._fwd_loss_bwd(g["lr"], g["hr"], g["tape"], g["dout"], self._scratch[1024:1025], on_bucket=boundary)
-                    finally:
-                        if state["open"] < len(graphs):         # an error left a capture open: close it before re-raising
-                            try:
+                    except BaseException as e:
+                        # A failed capture must not leave a stream in capture mode: the backward pass has stopped at the failing
+                        # boundary (nothing was enqueued after it), so end whatever capture is still open, drop every graph of this
+                        # attempt and wait for the device before handing the error on (an error of the clean-up itself is chained).
+                        try:
+                            if state["open"] < len(graphs):
                                 graphs[state["open"]].capture_end()
-                            except Exception:                   # noqa: BLE001
-                                pass
+                        except BaseException as e2:            # noqa: BLE001
+                            e.__context__ = e2
+                        finally:
+                            graphs.clear()
+                            torch.cuda.synchronize(dev)
+                        raise
                 torch.cuda.current_stream(dev).wait_stream(side)
                 g["graphs"] = graphs
             g["buckets"] = [grad_bucket(self.s, b) for b in range(_lib.GRAD_BUCKETS)]
@@ -275,7 +284,7 @@ class TrainStep:
         B, _, H, W = lr_in.shape
         h, w = H // self.A, W // self.A
         L = _lib.lib()
-        exchange = dp.dp_active(self.group)
+        exchange = self.exchange and dp.dp_active(self.group)
         handles = []
 
         def start_bucket(bucket, first, count):                # the all-reduce of a finished bucket, beside the rest of the backward

@@ -123,9 +123,14 @@ def mha(q_in: torch.Tensor, v_in: torch.Tensor, w_in: torch.Tensor, w_out: torch
 # layout of the pre-activation}, the activation uses the GIVEN branch (True = positive side) instead of sign(z), so a
 # backward pass can be checked exactly against an implementation whose forward made the decisions.
 branch_masks: Optional[dict] = None
+# When a dict: every activation records its pre-activation tensor under its tag (tests compare the oracle's branch decisions
+# with the reference's, tests/golden/train_kink_*.npz).
+branch_record: Optional[dict] = None
 
 
 def _act(z: torch.Tensor, tag: str, slope: float) -> torch.Tensor:
+    if branch_record is not None:
+        branch_record[tag] = z.detach().clone()
     if branch_masks is not None and tag in branch_masks:
         m = branch_masks[tag].to(z.dtype)
         return z * (m + (1.0 - m) * slope)

@@ -35,8 +35,14 @@ def test_forward_matches_reference_fixture(name, precision, golden_dir):
         out = net(lr).cpu()
     ref = torch.from_numpy(g["out"])
     rel = float((out - ref).abs().max() / ref.abs().max())
-    print(f"{name} [{precision}] rel max err {rel:.3e}  psnr(ours, reference) {O.psnr(out, ref):.2f} dB")
+    # "1e-3 relative" is applied in the max norm, max|err| / max|ref| (the output lives in [0, 1]: an absolute bound).  The
+    # element-wise relative error is reported beside it on the pixels that are not dark (|ref| >= 0.05) and gated loosely.
+    m = ref.abs() >= 0.05
+    ew = (out - ref).abs()[m] / ref.abs()[m]
+    print(f"{name} [{precision}] rel max err {rel:.3e}  element-wise rel err on |ref|>=0.05: max {float(ew.max()):.3e} mean {float(ew.mean()):.3e} "
+          f"({int(m.sum())} px)  psnr(ours, reference) {O.psnr(out, ref):.2f} dB")
     assert out.shape == ref.shape
+    assert float(ew.max()) <= {"fp32": 1e-4, "fp16": 2e-2, "bf16": 5e-2}[precision]
     # north_star: 1e-3 relative -- met by the fp32 path (observed 3e-7) and by the fp16 path (11 significant bits, ~2e-4).  The bf16
     # path rounds every MFMA operand and every inter-kernel tensor to 8 significant bits: 1.5e-3 .. 1.9e-3 observed, which does NOT
     # meet 1e-3; its gate only pins that level.
@@ -162,9 +168,11 @@ def test_pipelined_forward_matches_plain_forward():
 
 
 def test_graph_refuses_replay_after_weights_change():
-    """A captured forward has the packed-weight buffer's address baked in; once the weights are re-packed or dropped
-    (optimizer step, load_state_dict) a replay must fail loudly instead of reading freed memory."""
-    from lft_amd.module import GraphedForward
+    """A captured forward has the packed-weight buffer's address baked in; once the weights are re-packed, dropped or merely
+    changed in place (optimizer step, load_state_dict) a replay must fail loudly instead of reading freed memory or silently
+    using the old weights -- also when NO eager forward ran in between (nothing has re-packed yet: only the parameters'
+    version counters tell)."""
+    from lft_amd.module import GraphedForward, PipelinedForward
     A, s, B, h, w = 2, 2, 1, 8, 8
     net = make_net(A, s, 1, "default", "bf16")
     lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=0)).to("cuda:0")
@@ -172,14 +180,121 @@ def test_graph_refuses_replay_after_weights_change():
         g = GraphedForward(net, lr)
         a = g(lr).clone()
         assert torch.equal(a, net(lr))
-        with torch.no_grad():
-            next(net.parameters()).mul_(1.5)          # in-place change: the next forward re-packs into a new buffer
-        b = net(lr)
+        assert torch.equal(g(lr), a)                  # an eager forward with unchanged weights does not invalidate the graph
+        next(net.parameters()).mul_(1.5)              # in-place change, no forward afterwards: net._packed is still the captured buffer
+        with pytest.raises(RuntimeError):
+            g(lr)
+        b = net(lr)                                   # re-packs into a new buffer
         assert not torch.equal(a, b)
         with pytest.raises(RuntimeError):
             g(lr)
         g2 = GraphedForward(net, lr)
         assert torch.equal(g2(lr), b)
+        pipe = PipelinedForward(net, lr, depth=2)
+        pipe(lr); pipe.sync()
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        net.load_state_dict(sd)                       # same values, but copied in place: the versions moved
+        with pytest.raises(RuntimeError):
+            g2(lr)
+        with pytest.raises(RuntimeError):
+            pipe(lr)
+
+
+def test_fp16_overflow_is_a_loud_error():
+    """The fp16 path's range ends at 65504.  Scale one FFN weight up until an activation leaves it: from then on the forward
+    must raise (the kernels' sticky status word, read after every eager fp16 forward) -- at no gain may it return inf / NaN or a
+    wrong image silently.  The exact-fp32 path of the same weights stays finite and is the checker."""
+    from lft_amd.module import GraphedForward
+    A, s, B, h, w = 5, 2, 1, 8, 8
+    lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=0)).to("cuda:0")
+    n16 = make_net(A, s, 1, "default", "fp16")
+    n32 = make_net(A, s, 1, "default", "fp32")
+    assert n16.check_finite and not n32.check_finite
+    key = "altblock.1.spa_trans.feed_forward.1.weight"          # FFN hidden layer: the largest activations of the network
+    base = {k: v.clone() for k, v in n16.state_dict().items()}
+    tripped_at, gain = None, 1.0
+    with torch.no_grad():
+        for _ in range(14):
+            for net in (n16, n32):
+                sd = {k: v.clone() for k, v in base.items()}
+                sd[key] = sd[key] * gain
+                net.load_state_dict(sd)
+            ref = n32(lr)
+            assert bool(torch.isfinite(ref).all())
+            try:
+                out = n16(lr)
+            except _lib.LftError as e:
+                assert "fp16 range" in str(e) and "65504" in str(e)
+                tripped_at = gain
+                break
+            assert bool(torch.isfinite(out).all()), gain
+            rel = float((out - ref).abs().max() / ref.abs().max())
+            print(f"gain {gain:g}: fp16 vs fp32 rel max err {rel:.2e}")
+            assert rel <= 2e-2, (gain, rel)                        # not overflowed: still the right image
+            gain *= 4.0
+    assert tripped_at is not None and tripped_at > 1.0, "the weights were never large enough to leave the fp16 range"
+    print(f"fp16 overflow reported at gain {tripped_at:g}")
+    with torch.no_grad():
+        # the status word was cleared by the failed check: a captured graph of the same (bad) weights replays silently but its
+        # check() raises; the C-ABI entry points say the same thing
+        n16.check_finite = False
+        g = GraphedForward(n16, lr)
+        g(lr)
+        with pytest.raises(_lib.LftError):
+            g.check()
+        n16.check_status()                                       # cleared again: no new forward, no error
+        # the fp32 and bf16 paths take the same weights without overflow (range 3e38)
+        nb = make_net(A, s, 1, "default", "bf16")
+        sd = {k: v.clone() for k, v in base.items()}
+        sd[key] = sd[key] * tripped_at
+        nb.load_state_dict(sd)
+        assert bool(torch.isfinite(nb(lr)).all())
+        nb.check_status()
+        # good weights again: the fp16 path works and reports nothing
+        n16.load_state_dict(base)
+        n16.check_finite = True
+        out = n16(lr)
+        assert bool(torch.isfinite(out).all())
+        # non-finite INPUT data is reported too, in every precision
+        bad = lr.clone()
+        bad[0, 0, 3, 3] = float("nan")
+        nb.load_state_dict(base)
+        nb(bad)
+        with pytest.raises(_lib.LftError):
+            nb.check_status()
+
+
+def test_status_word_through_the_c_abi():
+    """lft_status_reset / lft_status_read on a caller-owned workspace: clear after a clean forward, LFT_STATUS_NONFINITE (1001)
+    after a forward on an input holding inf, clear again after a reset."""
+    import ctypes
+    A, s, B, h, w = 2, 2, 1, 8, 8
+    prec = _lib.PREC_F16
+    sd = deterministic_state(64, s, seed=1)
+    from lft_amd.params import param_table
+    params = [torch.from_numpy(sd[n]).to("cuda:0") for n, _, _ in param_table(64, s)]
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    packed = torch.empty(_lib.packed_bytes(A, h, w, s, prec), dtype=torch.uint8, device="cuda:0")
+    arr = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+    _lib.check(L.lft_pack_weights(arr, len(params), packed.data_ptr(), A, h, w, s, prec, st), "pack")
+    work = torch.empty(_lib.workspace_bytes(B, A, h, w, s, prec), dtype=torch.uint8, device="cuda:0")
+    work.fill_(0xFF)                                              # garbage, as a fresh allocation may hold
+    dims = (B, A, h, w, s, prec)
+    _lib.check(L.lft_status_reset(work.data_ptr(), *dims, st), "reset")
+    lr = torch.from_numpy(synthetic_lr(B, A, h, w, seed=0)).to("cuda:0")
+    out = torch.empty(B, 1, A * h * s, A * w * s, device="cuda:0")
+    flags = ctypes.c_uint(7)
+    _lib.check(L.lft_forward(packed.data_ptr(), lr.data_ptr(), out.data_ptr(), work.data_ptr(), *dims, st), "forward")
+    assert L.lft_status_read(work.data_ptr(), *dims, st, ctypes.byref(flags)) == 0 and flags.value == 0
+    lr[0, 0, 5, 5] = float("inf")
+    _lib.check(L.lft_forward(packed.data_ptr(), lr.data_ptr(), out.data_ptr(), work.data_ptr(), *dims, st), "forward")
+    assert L.lft_status_read(work.data_ptr(), *dims, st, ctypes.byref(flags)) == _lib.STATUS_NONFINITE and flags.value == 1
+    assert b"non-finite" in L.lft_last_error()
+    assert L.lft_status_read(work.data_ptr(), *dims, st, None) == _lib.STATUS_NONFINITE      # sticky until reset
+    _lib.check(L.lft_status_reset(work.data_ptr(), *dims, st), "reset")
+    assert L.lft_status_read(work.data_ptr(), *dims, st, ctypes.byref(flags)) == 0 and flags.value == 0
+    assert L.lft_status_read(None, *dims, st, None) == -1
 
 
 def test_bench_spawns_its_own_ranks():
@@ -202,3 +317,16 @@ def test_bench_spawns_its_own_ranks():
     assert j["n_gpus"] == 2 and j["steps"] == 10 and j["config"]["global_batch"] == 8 and j["scaling"] == "weak"
     assert j["value"] > 0 and "roofline" in j and "rehearsal" in j
     assert abs(j["value"] - 2 * 4 * 10 / (j["ms_per_step"] * 10 / 1e3)) < 1e-6 * j["value"]
+    assert len(j["per_rank_ms"]) == 2 and abs(max(j["per_rank_ms"]) - j["ms_per_step"]) < 1e-6 * j["ms_per_step"]
+    assert j["config"]["name"] == "cfg2"
+    # the training configuration by name: 2 ranks, bucketed gradient exchange (gloo through the host in this rehearsal)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "cfg3", "--batch", "1", "--steps", "4", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["name"] == "cfg3" and j["config"]["global_batch"] == 2 and "training" in j["metric"]
+    ar = j["allreduce"]
+    assert ar and sum(ar["buckets_bytes"]) == 4 * 1_114_240 and ar["ms_alone"] > 0 and ar["step_ms_with_exchange"] > 0
+    assert len(j["per_rank_ms"]) == 2 and j["value"] > 0 and j["loss"] > 0

@@ -58,7 +58,26 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.lib().lft_version() == 3
+    assert _lib.lib().lft_version() == _lib.ABI_VERSION == 4
+
+
+def test_stale_library_and_changed_flags_are_noticed(monkeypatch):
+    """A library that reports another ABI version is refused at load time (its entry points may take other arguments), and a
+    change of the compiler flags -- which live in _lib.py, not in a source file -- makes needs_build() true."""
+    _lib.build()
+    assert not _lib.needs_build()
+    monkeypatch.setitem(_lib.UNIT_FLAGS, 1, ["-fno-slp-vectorize", "-DSOMETHING_ELSE"])
+    assert _lib.needs_build()
+    monkeypatch.undo()
+    assert not _lib.needs_build()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", 99)
+    with pytest.raises(_lib.LftError, match="ABI version"):
+        _lib.lib()
+    monkeypatch.undo()
+    L = _lib.lib()
+    assert L.lft_status_read(None, 1, 5, 8, 8, 2, _lib.PREC_F16, None, None) == -1        # argument check before any device work
+    assert L.lft_status_reset(None, 1, 5, 8, 8, 2, _lib.PREC_F16, None) == -1
 
 
 def test_size_queries_and_argument_errors():

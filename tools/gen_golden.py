@@ -171,6 +171,73 @@ def train_case(ref, name, A, s, B, h, w, wseed=1, iseed=0, tseed=2, flavor="stre
     print(f"{name}: losses {losses} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+KINK_TAU = 5e-4           # pre-activations closer to 0 than this are listed unit by unit in the kink fixtures
+KINK_CHUNK = 4096         # flat units per entry of the popcount table
+
+
+def kink_tags(net):
+    """(tag, module whose OUTPUT is the pre-activation of a ReLU / LeakyReLU), in the layouts the reference computes them:
+    conv{0,2,4}: [B,64,V,h,w]; ang{l}: [V, B*h*w, 128]; spa{l}: [h*w, B*V, 256]; up: [B, 64 s^2, A*h, A*w]."""
+    tags = [(f"conv{i}", net.conv_init[i]) for i in (0, 2, 4)]
+    for l, blk in enumerate(net.altblock):
+        tags.append((f"ang{l}", blk.ang_trans.feed_forward[1]))
+        tags.append((f"spa{l}", blk.spa_trans.feed_forward[1]))
+    tags.append(("up", net.upsampling[0]))
+    return tags
+
+
+def train_kink_case(ref, name, A, s, B, h, w, wseed=1, iseed=0, tseed=2, flavor="stress"):
+    """The reference's gradients on an UNSCREENED input, together with what an independent implementation needs to be held
+    to 1e-3 on it although the network is piecewise linear: for every ReLU / LeakyReLU of the network the branch the reference
+    took at every unit -- as a SHA-256 of the sign bitmap with the near-zero units (|z| < KINK_TAU) masked out, a popcount per
+    4096 units to localise a mismatch, and the near-zero units themselves (flat index in the reference's layout, signed z).
+    Data only: no reference code."""
+    import hashlib
+    net = ref.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=s))
+    sd = deterministic_state(64, s, seed=wseed, flavor=flavor)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.train()
+    lr_in = torch.from_numpy(synthetic_lr(B, A, h, w, seed=iseed))
+    rng = np.random.Generator(np.random.PCG64([tseed, B, A, h, w, s]))
+    hr = torch.from_numpy(rng.random((B, 1, A * h * s, A * w * s), dtype=np.float32))
+    pre = {}
+    hooks = []
+    for tag, mod in kink_tags(net):
+        hooks.append(mod.register_forward_hook(lambda _m, _i, o, tag=tag: pre.__setitem__(tag, o.detach().clone())))   # before the in-place activation
+    crit = ref.get_loss(None)
+    out = net(lr_in)
+    loss = crit(out, hr)
+    loss.backward()
+    for x in hooks:
+        x.remove()
+    # hr is not stored: the tests regenerate it from tseed with the generator above
+    rec = {"meta": np.array([A, s, B, h, w, wseed, iseed, tseed, 1], dtype=np.int64), "flavor": np.array(flavor), "hr_sum": np.array(float(hr.double().sum())),
+           "losses": np.array([float(loss)], dtype=np.float64), "kink_tau": np.array(KINK_TAU), "kink_chunk": np.array(KINK_CHUNK)}
+    rec["l1_min_abs_diff"] = np.array(float((out.detach() - hr).abs().min()))          # the loss has a kink too (sign of sr - hr)
+    for k, p in net.named_parameters():
+        g = p.grad.detach().contiguous().numpy().ravel()
+        rec[f"grad_{k}_sub"] = g[sub_indices(g.size)]
+        rec[f"grad_{k}_stats"] = stats(g)
+        if g.size <= 1024:
+            rec[f"grad_{k}_full"] = g.copy()
+    n_near = 0
+    for tag, z in pre.items():
+        z = z.contiguous().numpy().ravel()
+        near = np.nonzero(np.abs(z) < KINK_TAU)[0]
+        bits = z > 0
+        bits[near] = False
+        pad = (-bits.size) % KINK_CHUNK
+        rec[f"kink_{tag}_shape"] = np.array(pre[tag].shape, dtype=np.int64)
+        rec[f"kink_{tag}_near_idx"] = near.astype(np.int32)
+        rec[f"kink_{tag}_near_z"] = z[near].astype(np.float32)
+        rec[f"kink_{tag}_sha256"] = np.frombuffer(hashlib.sha256(np.packbits(bits).tobytes()).digest(), dtype=np.uint8).copy()
+        rec[f"kink_{tag}_popcount"] = np.concatenate([bits, np.zeros(pad, dtype=bool)]).reshape(-1, KINK_CHUNK).sum(1).astype(np.uint16)
+        n_near += near.size
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: loss {float(loss):.6f}, {n_near} units within {KINK_TAU} of a kink -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def main():
     torch.set_num_threads(8)
     ref = load_reference()
@@ -184,6 +251,12 @@ def main():
         # fp64 agree to 1.9e-4 of every tensor's scale on this input (seeds 0..5, 7 have a unit within fp32 rounding of a ReLU
         # kink: 3.5e-4 .. 9e-4 between fp32 and fp64 themselves), so an independent implementation can be held to 1e-3 outright
         train_case(ref, "train_a5_s2_b2_16x16", 5, 2, 2, 16, 16, iseed=6, adam_steps=1)
+        return
+    if "--train-kink-only" in sys.argv:
+        # the same shape on UNSCREENED input seeds, with the reference's branch decisions (tests/test_gpu_train.py:
+        # test_gradients_on_unscreened_inputs_with_aligned_kinks)
+        for iseed in (0, 1, 2):
+            train_kink_case(ref, f"train_kink_a5_s2_b2_16x16_seed{iseed}", 5, 2, 2, 16, 16, iseed=iseed)
         return
     if "--wide-only" in sys.argv:      # add the h < w fixture without rewriting the others
         run_case(ref, "wide_a2_s2_b1_6x12", 2, 2, 1, 6, 12, full_taps=True)
@@ -202,6 +275,8 @@ def main():
     train_case(ref, "train_a2_s4_b1_8x5", 2, 4, 1, 8, 5)
     train_case(ref, "train_a5_s2_b2_16x16", 5, 2, 2, 16, 16, iseed=6, adam_steps=1)
     run_case(ref, "cfg2_a5_s4_b1_32x32", 5, 4, 1, 32, 32, flavor="default")   # one patch of configs[1]
+    for iseed in (0, 1, 2):
+        train_kink_case(ref, f"train_kink_a5_s2_b2_16x16_seed{iseed}", 5, 2, 2, 16, 16, iseed=iseed)
 
 
 if __name__ == "__main__":

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Diagnostic: build liblft_hip with -DLFT_STAMPS, run one spatial block, print mean cycles between the
+"""Diagnostic: build liblft_hip with -DLFT_EXPERIMENT, run one spatial block, print mean cycles between the
 LFT_STAMP() points of k_spa1 / k_spa2 (wave 0 of each workgroup).  GPU box only; never quote its run time."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 so = os.path.join(ROOT, "gpurun_out", "liblft_hip_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLFT_STAMPS",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLFT_EXPERIMENT",
                        os.path.join(ROOT, "lft_amd", "csrc", "lft_api.hip"), "-o", so])
 from lft_amd import _lib
 _lib.LIB_PATH = so
