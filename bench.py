@@ -49,18 +49,20 @@ A, S, H, W = 5, 4, 32, 32          # BASELINE.json metric: 5x5 angRes, 32x32 LR,
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 
 
-def flops_per_token(s: int, V: int, wbar: float) -> dict:
+def flops_per_token(s: int, V: int, wbar: float, q_in_part_b: bool = True) -> dict:
     """Algorithmic FLOPs (2*MAC) per token and kernel, SURVEY.md 8(d): window-limited attention,
-    LN/softmax/activations excluded, position-token embedding excluded (cached)."""
+    LN/softmax/activations excluded, position-token embedding excluded (cached).  q_in_part_b (the 16-bit paths on
+    32-column-aligned views, i.e. every BASELINE shape): the Q projection runs in k_spa_b, not in k_spa1."""
     C, E = 64, 128
+    qa, qb = (4, 2) if q_in_part_b else (6, 0)
     return {
         "k_conv0": 18 * C,
         "k_conv64": 18 * C * C,
         "k_ang": 16 * C * C + 4 * V * C,
-        "k_spa1": 18 * C * E + 6 * E * E,
+        "k_spa1": 18 * C * E + qa * E * E,
         "k_spa_attn": 4 * wbar * E,
         "k_spa2": 2 * E * E + 8 * E * E + 2 * E * C,
-        "k_spa_b": 4 * wbar * E + 2 * E * E + 8 * E * E + 2 * E * C,     # bf16: attention + out_proj + FFN + 1x1x1 in one kernel
+        "k_spa_b": 4 * wbar * E + qb * E * E + 2 * E * E + 8 * E * E + 2 * E * C,     # 16-bit: (Q +) attention + out_proj + FFN + 1x1x1 in one kernel
         "k_up": 2 * C * C * s * s + 18 * C * s * s,
         "k_assemble": 32 * s * s,
     }
@@ -68,16 +70,18 @@ def flops_per_token(s: int, V: int, wbar: float) -> dict:
 
 def bytes_per_token(s: int, esz: int) -> dict:
     """Algorithmic HBM bytes per token and kernel: every activation tensor a kernel must read or write once
-    (esz = bytes per stored activation element; weights and tables are amortised over the batch and ignored)."""
+    (esz = bytes per stored activation element; weights and tables are amortised over the batch and ignored).  16-bit paths:
+    Q never exists in memory (k_spa1 writes tok, K, V; k_spa_b reads them)."""
     C, E, gp = 64, 128, (s + 2) * (s + 2)
+    nqkv = 3 if esz == 2 else 4
     return {
         "k_conv0": 4 + C * esz,                       # LR pixel in, 64-channel token out
         "k_conv64": 2 * C * esz,                      # token in, token out (the residual read of the 3rd conv is ignored)
         "k_ang": 2 * C * esz,
-        "k_spa1": C * esz + 4 * E * esz,              # x in; tok, Q, K, V out
+        "k_spa1": C * esz + nqkv * E * esz,           # x in; tok, (Q,) K, V out
         "k_spa_attn": 4 * E * esz,                    # Q, K, V in (halo re-reads are not algorithmic); O out
         "k_spa2": 2 * E * esz + C * esz,              # tok, O in; x out
-        "k_spa_b": 4 * E * esz + C * esz,             # tok, Q, K, V in (halo re-reads are not algorithmic); x out
+        "k_spa_b": 3 * E * esz + C * esz,             # tok, K, V in (halo re-reads and the second read of tok are not algorithmic); x out
         "k_up": C * esz + gp * 4,                     # x in; (s+2)^2 fp32 footprint out
         "k_assemble": gp * 4 + 4 + s * s * 4,         # footprint + LR pixel in; s*s HR pixels out
     }
@@ -139,7 +143,7 @@ def cpu_baseline(seconds: float, lr=None):
             "sample": f"{n} single-patch forwards (A{A}, {S}x, {H}x{W} LR, fp32, torch {torch.__version__} CPU ops) in {dt:.1f} s"}, ref
 
 
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
 
 
 def source_hash() -> str:
@@ -162,8 +166,8 @@ def traffic_from_profile(kernel: str, args) -> dict:
         prof = json.load(open(TRAFFIC_PROFILE))
         k = prof["kernels"].get(kernel)
         if k and prof.get("source_hash") == cur:
-            return {"traffic": k["total"], "traffic_source": "profiles/r02_hbm_traffic.json", "source_hash": cur}
-        return {"traffic": None, "traffic_note": "profiles/r02_hbm_traffic.json was taken on other sources (hash %s)" % prof.get("source_hash"),
+            return {"traffic": k["total"], "traffic_source": "profiles/r03_hbm_traffic.json", "source_hash": cur}
+        return {"traffic": None, "traffic_note": "profiles/r03_hbm_traffic.json was taken on other sources (hash %s)" % prof.get("source_hash"),
                 "source_hash": cur}
     return {"traffic": None, "source_hash": cur}
 
@@ -483,7 +487,7 @@ def main():
     if rank == 0:
         V = A * A
         ntok = args.batch * V * H * W
-        fpt = flops_per_token(S, V, mean_window(H, W))
+        fpt = flops_per_token(S, V, mean_window(H, W), q_in_part_b=args.precision != "fp32" and W % 32 == 0 and (H * W) % 128 == 0)
         with torch.no_grad():
             kb = kernel_breakdown(net, lr, reps=10)
         total_ms = sum(ms * cnt for ms, cnt in kb.values())

@@ -106,7 +106,7 @@ int make_dims(int B, int A, int h, int w, int s, int prec, Dims* d) {
 }
 
 // Fragment counts per stream
-constexpr int kFragsConv = 72, kFragsAng = 64, kFragsSpa1 = 240, kFragsSpa2 = 176;
+constexpr int kFragsConv = 72, kFragsAng = 64, kFragsSpa1 = 240, kFragsSpa1NoQ = 208, kFragsSpa2 = 176;
 inline int frags_up(const Dims& d) { return d.nchunk * (4 + 2 * d.gt); }
 
 struct PackedLayout {
@@ -238,10 +238,12 @@ int launch_spa1(unsigned nwg, const T* in, const T* ws, const float* ln, const T
     const bool use8 = (l16 > share && l8 <= share) || l16 > kMaxLds;
     int rc;
     const bool lm = !PE_ONLY && tok_lane_major<T>(d);      // hand the token tile to part B in lane-major tile form
+    // 16-bit with the lane-major hand-off: part B (k_spa_b) computes Q from the token tile itself; k_spa1 then skips that projection
 #define LFT_LAUNCH_SPA1(CHV, LMV, LDSV)                                                                                     \
     do {                                                                                                                    \
-        if ((rc = allow_lds(k_spa1<T, PE_ONLY, CHV, LMV>, LDSV, "k_spa1"))) return rc;                                      \
-        k_spa1<T, PE_ONLY, CHV, LMV><<<nwg, 64 * kNwSpa1, LDSV, st>>>(in, ws, ln, petok, tok, q, k, v, pe_out, nimg, d.h, d.w, status); \
+        constexpr bool WQ = !(LMV && sizeof(T) == 2);                                                                       \
+        if ((rc = allow_lds(k_spa1<T, PE_ONLY, CHV, LMV, WQ>, LDSV, "k_spa1"))) return rc;                                  \
+        k_spa1<T, PE_ONLY, CHV, LMV, WQ><<<nwg, 64 * kNwSpa1, LDSV, st>>>(in, ws, ln, petok, tok, q, k, v, pe_out, nimg, d.h, d.w, status); \
     } while (0)
     if (use8) { if (lm) LFT_LAUNCH_SPA1(8, true, l8); else LFT_LAUNCH_SPA1(8, false, l8); }
     else { if (lm) LFT_LAUNCH_SPA1(16, true, l16); else LFT_LAUNCH_SPA1(16, false, l16); }
@@ -289,8 +291,8 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
             std::vector<PackOp> ops;
             conv_ops(ops, q[0], 128);
             ops.push_back(lin_op(q[3], 256, 128, 128, 0, 8, 1, 1.0f));          // Wv (consumed first)
-            ops.push_back(lin_op(q[3], 0, 128, 128, 0, 8, 1, kSpaScale));      // Wq
             ops.push_back(lin_op(q[3], 128, 128, 128, 0, 8, 1, 1.0f));          // Wk
+            ops.push_back(lin_op(q[3], 0, 128, 128, 0, 8, 1, kSpaScale));      // Wq: last -- k_spa1's ring ends before it when part B computes Q itself (kFragsSpa1NoQ)
             if ((rc = run_pack<T>(ops, at<T>(packed, L.s_spa1[l]), kFragsSpa1, st))) return rc;
         }
         {   // spatial part 2: out_proj, FFN in 4 chunks, 1x1x1 conv.  out_proj's operand: bf16 -- the attention accumulators
@@ -418,7 +420,8 @@ int spa_part_b(const void* packed, const PackedLayout& L, int l, const T* skip, 
 #define LFT_LAUNCH_SPAB(SKV, LMV, YLV)                                                                                      \
     do {                                                                                                                    \
         if ((rc = allow_lds(k_spa_b<T, SKV, LMV, YLV>, lds, "k_spa_b"))) return rc;                                            \
-        k_spa_b<T, SKV, LMV, YLV><<<ntile, 256, lds, st>>>(tok, q, k, v, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.h, d.w, at<unsigned>(ws, W.status)); \
+        k_spa_b<T, SKV, LMV, YLV><<<ntile, 256, lds, st>>>(tok, q, k, v, at<T>(packed, L.s_spa2[l]), ln, skip, out, d.h, d.w, at<unsigned>(ws, W.status), \
+                                                           at<T>(packed, L.s_spa1[l]) + (size_t)kFragsSpa1NoQ * 512, at<T>(packed, L.petok[l])); \
     } while (0)
         const bool tlm = tok_lane_major<T>(d);
         if (out_lm && !(skip && tlm)) return fail(LFT_ERR_ARG, "internal: lane-major output needs the skip variant and lane-major tokens");

@@ -19,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 
 typedef __bf16 bf16_t;
 // Register pairs for the vector-instruction-bound phases.  LFT_PK = 1: a real 2-vector (v_pk_add_f32 / v_pk_mul_f32 /
@@ -212,6 +213,13 @@ LFT_DEV void wait_vmcnt(int n) {
 // "memory" clobber keeps the compiler from moving LDS/global accesses across it; LDS-DMA completion is handled
 // explicitly by the counted wait in WRing.
 LFT_DEV void wg_barrier_keep_vm() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// The same with the LDS wait as a builtin (0xC07F = lgkmcnt(0), vmcnt / expcnt untouched): hipcc's wait-count bookkeeping then
+// KNOWS that every earlier ds_read has returned.  After the all-asm form it re-waits for register sets fetched a boundary ago
+// -- and, with younger reads in flight, does so with lgkmcnt(0): the pipelined ring's fetch latency exposed again.
+LFT_DEV void wg_barrier_keep_vm_lds_visible() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    asm volatile("s_barrier" ::: "memory");
+}
 
 // Weight ring: the 4 waves of a workgroup consume the same fragment stream in lock-step.  The stream is cut
 // into chunks of CH fragments held in a 3-slot LDS ring: while chunk c feeds the MFMAs, chunks c+1 and c+2 are
@@ -275,23 +283,33 @@ struct WRing {
 };
 
 
-// Deep variant of the weight ring for kernels that can spare LDS: NBUF slots, DMA issued NBUF - 1 chunks ahead (the
-// L2 -> LDS latency under load is several chunk times; with the 3-slot ring every chunk boundary stalled on it).  The
-// slots may live in two separate LDS regions (slots >= split_slot are shifted by split_gap bytes), and the first
-// NBUF - 1 chunks are issued by the caller (issue(c)) as the regions become free -- see k_spa_b.  Same lock-step and
-// counted-vmcnt rules as WRing; VM operations the kernel issues in between only make the waits stricter.
-template <typename T, int CH, int NW, int NBUF>
-struct WRingDeep {
+// Register-pipelined weight ring.  WRing reads a chunk's fragments from LDS right behind the barrier that publishes
+// it, so every chunk boundary costs a barrier, an LDS round trip and only then the chunk's MFMAs (~700 cycles per 8-fragment
+// chunk of which 256 are matrix work: in-kernel stamps).  Here the fragments of chunk c+1 are fetched into a SECOND register set
+// at the boundary in front of chunk c's MFMAs, which then run from registers loaded one boundary earlier: the LDS latency and
+// the barrier skew hide under matrix work.  Costs CH fragments of registers.  A chunk's slot is free as soon as every wave
+// holds it in registers, i.e. at the next boundary (the barrier helper waits lgkmcnt(0) first): the DMA runs NBUF chunks ahead.
+// Every position is a TEMPLATE argument (get<POS>()): the two register sets are only ever indexed by constants, whatever the
+// optimiser does (with a run-time position member the sets ended up in scratch).  Protocol: setup(); issue(0 .. NBUF-1) by the
+// caller as the slots become available; start(); then get<0>(), get<1>(), ... in order, at the same program points in every
+// wave (linear_ring_at).  NFRAG = fragments in the stream.
+template <typename T, int CH, int NW, int NBUF, int NFRAG>
+struct WRingPipe {
     static constexpr int FRAG_BYTES = 1024 * FragInfo<T>::PIECES;
     static constexpr int CHUNK_BYTES = CH * FRAG_BYTES;
+    static constexpr int LDS_BYTES = NBUF * CHUNK_BYTES;
     static constexpr int PIECES_PER_WAVE = CH * FragInfo<T>::PIECES / NW;
+    static constexpr int NCHUNK = (NFRAG + CH - 1) / CH;
     static_assert((CH * FragInfo<T>::PIECES) % NW == 0, "chunk must split over the workgroup's waves");
-    static_assert(PIECES_PER_WAVE * (NBUF - 2) <= 63, "counted vmcnt immediate");
+    static_assert(PIECES_PER_WAVE * (NBUF - 1) <= 63, "counted vmcnt immediate");
+    static constexpr int cmin(int a, int b) { return a < b ? a : b; }
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
     const char* g;
     char* lds;
-    int lane, wave, pos, nfrag, split_slot, split_gap;
-    LFT_MEM void setup(const T* stream, char* lds_base, int total_frags, int split_slot_, int split_gap_) {
-        g = reinterpret_cast<const char*>(stream); lds = lds_base; nfrag = total_frags; pos = 0;
+    int lane, wave, split_slot, split_gap;
+    Frag<T> fr0[CH], fr1[CH];
+    LFT_MEM void setup(const T* stream, char* lds_base, int split_slot_ = NBUF, int split_gap_ = 0) {
+        g = reinterpret_cast<const char*>(stream); lds = lds_base;
         split_slot = split_slot_; split_gap = split_gap_;
         lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -301,37 +319,62 @@ struct WRingDeep {
         return lds + s * CHUNK_BYTES + (s >= split_slot ? split_gap : 0);
     }
     LFT_MEM void issue(int c) {                                         // every wave issues exactly PIECES_PER_WAVE pieces per existing chunk
-        if (c * CH >= nfrag) return;
+        if (c * CH >= NFRAG) return;
         const char* src = g + (size_t)c * CHUNK_BYTES;
         char* dst = slot(c);
-        const int last = (nfrag - c * CH) * FragInfo<T>::PIECES - 1;
+        const int last = (NFRAG - c * CH) * FragInfo<T>::PIECES - 1;
 #pragma unroll
         for (int i = 0; i < PIECES_PER_WAVE; ++i) {
             const int piece = min(wave * PIECES_PER_WAVE + i, last);
             glds_piece(src + piece * 1024, dst + piece * 1024, lane);
         }
     }
-    LFT_MEM Frag<T> next() {
-        const int c = pos / CH, i = pos % CH;
-        if (i == 0) {
-            const int nchunk = (nfrag + CH - 1) / CH;
-            const int younger = max(0, min(NBUF - 2, nchunk - 1 - c));    // chunks c+1 .. c+NBUF-2 are in flight behind chunk c
-            wait_vmcnt(younger * PIECES_PER_WAVE);
-            wg_barrier_keep_vm();                                       // chunk c published, chunk c-1 retired by every wave
-            issue(c + NBUF - 1);                                        // into the slot chunk c-1 just vacated
+    template <int C> LFT_MEM void fetch() {                             // LDS -> register set C & 1; the reads are in flight on return
+        const char* base = slot(C);
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (C * CH + i < NFRAG) {
+                if constexpr (C & 1) fr1[i] = frag_from_pieces(base + i * FRAG_BYTES, lane, T());
+                else fr0[i] = frag_from_pieces(base + i * FRAG_BYTES, lane, T());
+            }
+    }
+    LFT_MEM void init(const T* stream, char* lds_base) {                // all slots free from the start
+        setup(stream, lds_base);
+#pragma unroll
+        for (int c = 0; c < NBUF; ++c) issue(c);
+    }
+    LFT_MEM void start() {                                              // chunks 0 .. NBUF-1 have been issued
+        wait_vmcnt(cmax(0, cmin(NBUF - 1, NCHUNK - 1)) * PIECES_PER_WAVE);
+        wg_barrier_keep_vm_lds_visible();
+        fetch<0>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int POS> LFT_MEM Frag<T> get() {
+        constexpr int C = POS / CH, I = POS % CH;
+        static_assert(POS >= 0 && POS < NFRAG, "position outside the stream");
+        if constexpr (I == 0 && C + 1 < NCHUNK) {
+            __builtin_amdgcn_sched_barrier(0);                          // chunk C-1's MFMAs are issued BEFORE the barrier: they execute while the wave waits in it
+            wait_vmcnt(cmax(0, cmin(NBUF - 2, NCHUNK - 2 - C)) * PIECES_PER_WAVE);   // chunks C+2 .. C+NBUF-1 stay in flight behind chunk C+1
+            wg_barrier_keep_vm_lds_visible();                           // chunk C+1 published; chunk C is in every wave's registers: its slot is free
+            issue(C + NBUF);
+            fetch<C + 1>();
+            // pin the fetch here: left alone, the scheduler sinks half of these reads to just in front of the NEXT boundary (fewer
+            // live registers), where the barrier's lgkmcnt(0) then waits for them -- the latency this ring exists to hide
+            __builtin_amdgcn_sched_barrier(0);
         }
-        ++pos;
-        return frag_from_pieces(slot(c) + i * FRAG_BYTES, lane, T());
+        if constexpr (C & 1) return fr1[I];
+        else return fr0[I];
     }
 };
-template <int NT_OUT, int KS, typename T, int CH, int NW, int NBUF>
-LFT_DEV void linear_ring(WRingDeep<T, CH, NW, NBUF>& ring, const Frag<T> (&x)[KS], f32x16 (&y)[NT_OUT]) {
-#pragma unroll
-    for (int nt = 0; nt < NT_OUT; ++nt)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) mma(ring.next(), x[ks], y[nt]);
+// Y^T[nt] += sum_ks W(nt, ks) x[ks] with the fragments at stream positions POS0 .. POS0 + NT_OUT * KS - 1 (nt-major)
+template <int POS0, int NT_OUT, int KS, typename Ring, typename T, int... I>
+LFT_DEV void linear_ring_seq(Ring& ring, const Frag<T> (&x)[KS], f32x16 (&y)[NT_OUT], std::integer_sequence<int, I...>) {
+    (mma(ring.template get<POS0 + I>(), x[I % KS], y[I / KS]), ...);
 }
-
+template <int POS0, int NT_OUT, int KS, typename Ring, typename T>
+LFT_DEV void linear_ring_at(Ring& ring, const Frag<T> (&x)[KS], f32x16 (&y)[NT_OUT]) {
+    linear_ring_seq<POS0, NT_OUT, KS>(ring, x, y, std::make_integer_sequence<int, NT_OUT * KS>());
+}
 // 8 consecutive channels of a token row in memory -> fragment in NATURAL k order (k = 8h + j);
 // used where an operand comes straight from HBM (attention output).  Branch-free: the caller passes an
 // address that is always readable (clamped for out-of-range lanes) and the result is zeroed by `ok`, so the
@@ -885,6 +928,31 @@ LFT_DEV void acc_frags(const f32x16 (&a)[NT], Frag<T> (&f)[2 * NT]) {
     for (int nt = 0; nt < NT; ++nt) {
         f[2 * nt] = acc_to_frag(a[nt], 0, T());
         f[2 * nt + 1] = acc_to_frag(a[nt], 1, T());
+    }
+}
+
+// ReLU'd activation as fragments.  16-bit operands: convert first, then ReLU on the PACKED halves as signed 16-bit integers
+// (v_pk_max_i16 against 0: a negative bf16 / f16 has its sign bit set, i.e. is a negative integer; -0.0 becomes +0) -- one
+// instruction per two values instead of one v_med3_f32 per value, in kernels bound by vector-instruction issue.  Rounding
+// and ReLU commute (rounding is monotonic and keeps the sign), so the fragments are bit-identical to relu-then-convert.
+template <int NT>
+LFT_DEV void acc_frags_relu(const f32x16 (&a)[NT], Frag<float> (&f)[2 * NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[2 * nt + s].lo[j] = relu_fast(a[nt][8 * s + j]); f[2 * nt + s].hi[j] = relu_fast(a[nt][8 * s + 4 + j]); }
+        }
+}
+template <int NT, typename T>
+LFT_DEV void acc_frags_relu(const f32x16 (&a)[NT], Frag<T> (&f)[2 * NT]) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    acc_frags<NT, T>(a, f);
+#pragma unroll
+    for (int k = 0; k < 2 * NT; ++k) {
+        const s16x8 v = __builtin_bit_cast(s16x8, f[k].v);
+        f[k].v = __builtin_bit_cast(typename H16<T>::v8, __builtin_elementwise_max(v, (s16x8)(0)));
     }
 }
 

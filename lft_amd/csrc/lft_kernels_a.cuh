@@ -202,9 +202,9 @@ constexpr int kConvZeroRow = 256;
 LFT_DEV void clear_zero_row(char* zero_row) {                          // call before the barrier that publishes the input tile
     if (threadIdx.x < kConvZeroRow / 16) store_raw16(zero_row + threadIdx.x * 16, raw16{0u, 0u, 0u, 0u});
 }
-template <int NT, typename T, int CH, int NW>
+template <int NT, typename T, int NW, typename Ring>
 LFT_DEV void conv3x3_tile(const char* lds_in, const char* zero_row, int tl, int y, int x, bool ok, int h, int w, int hh,
-                          WRing<T, CH, NW>& ring, f32x16 (&acc)[NT]) {
+                          Ring& ring, f32x16 (&acc)[NT]) {
     using CI = ConvIn<T, NW>;
     static_assert(CI::ROW_BYTES <= kConvZeroRow, "zero row too short");
 #pragma unroll
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv64(const T* __restrict__ in, T*
     __syncthreads();                                                                 // ... and everybody else's
     f32x16 acc[2];
     zero_acc<2>(acc);
-    conv3x3_tile<2, T>(lds_in, zero_row, tl, p / w, p % w, ok, h, w, hh, ring, acc);
+    conv3x3_tile<2, T, NW>(lds_in, zero_row, tl, p / w, p % w, ok, h, w, hh, ring, acc);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -414,11 +414,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
         zero_acc<4>(hid);
         linear_lds<4, 4, T>(smem, 32, lane, nf, hid);
         Frag<T> hf[8];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) hid[nt][i] = relu_fast(hid[nt][i]);
-        acc_frags<4, T>(hid, hf);
+        acc_frags_relu<4>(hid, hf);
         linear_lds<2, 8, T>(smem, 48, lane, hf, x);
         LFT_STAMP(5 + 5 * stamp_it);
         store_tile<2, T>(Y + off0, V, lane, x, scr, vstride);
@@ -593,11 +589,7 @@ __global__ __launch_bounds__(64 * CT * NG) void k_ang_multi(const T* __restrict_
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) mma(wfrag(32 + nt * 4 + ks), nf[ks], hid[nt]);
         Frag<T> hf[8];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) hid[nt][i] = relu_fast(hid[nt][i]);
-        acc_frags<4, T>(hid, hf);
+        acc_frags_relu<4>(hid, hf);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll

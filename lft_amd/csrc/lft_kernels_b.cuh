@@ -9,8 +9,10 @@
 //   tok = conv3x3(x; MLP.weight as [128,64,3,3])            (unfold + Linear 576->128)
 //   n   = LN(tok + PEtok[p])                                 (PEtok = same embedding of the position image, cached)
 //   Q = n Wq^T (pre-scaled by 1/4 * log2 e), K = n Wk^T, V = tok Wv^T
-// Stream: conv[36 x 4] Wv[4x8] Wq[4x8] Wk[4x8]  (240 fragments).
+// Stream: conv[36 x 4] Wv[4x8] Wk[4x8] Wq[4x8]  (240 fragments).
 // PE_ONLY: embed the position image itself and write the tokens (pack-time precompute).
+// WITH_Q = false (16-bit path with lane-major hand-off): Q is NOT produced here -- k_spa_b computes it from the token tile it
+// loads anyway (one tensor less written and read back: -52 MB per layer at B = 4); the ring then ends after Wk (208 fragments).
 // ------------------------------------------------------------------------------------------
 #ifndef LFT_UP_CHUNK
 #define LFT_UP_CHUNK 8
@@ -35,7 +37,7 @@ constexpr int kSpaChunk = LFT_SPA_CHUNK;   // fragments per ring chunk: one conv
 #define LFT_NW_UP 8      // k_up is light on registers: eight waves share one weight stream (48 -> 42 us at B = 4)
 #endif
 constexpr int kNwSpa1 = LFT_NW_SPA1, kNwSpa2 = LFT_NW_SPA2, kNwUp = LFT_NW_UP;
-template <typename T, bool PE_ONLY, int CH = kSpaChunk, bool TOKLM = false, int NW = kNwSpa1>   // TOKLM: the token tile goes to k_spa2 in lane-major tile format
+template <typename T, bool PE_ONLY, int CH = kSpaChunk, bool TOKLM = false, bool WITH_Q = true, int NW = kNwSpa1>   // TOKLM: the token tile goes to part B in lane-major tile format
 __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restrict__ X, const T* __restrict__ ws,
                                               const float* __restrict__ ln, const T* __restrict__ petok,
                                               T* __restrict__ TOK, T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vv,
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
     raw16 lnv = raw16{0u, 0u, 0u, 0u};
     if (!PE_ONLY) lnv = params_load(ln, 256);                         // norm.{weight,bias}; ln is null in the pack-time PE_ONLY launch
     WRing<T, CH, NW> ring;
-    ring.init(ws, smem, PE_ONLY ? 144 : 240);
+    ring.init(ws, smem, PE_ONLY ? 144 : (WITH_Q ? 240 : 208));
     stage_conv_input<T, NW>(X + (size_t)im * hw * 64, p0, hw, w, lds_in);
     clear_zero_row(zero_row);
     LFT_STAMP(12);
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
     LFT_STAMP(1);
     f32x16 t[4];
     zero_acc<4>(t);
-    conv3x3_tile<4, T>(lds_in, zero_row, tl, p / w, p % w, ok, h, w, hh, ring, t);
+    conv3x3_tile<4, T, NW>(lds_in, zero_row, tl, p / w, p % w, ok, h, w, hh, ring, t);
     LFT_STAMP(2);
     if (PE_ONLY) {
         store_lane_major<4, T>(pe_out + (size_t)((p0 >> 5) + wave) * 4096, lane, t);   // lane-major table, one 32-token tile per wave
@@ -112,17 +114,19 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
         f32x16 a[2];
         zero_acc<2>(a);
         linear_ring<2, 8, T>(ring, nf, a);
-        if constexpr (QKVLM) store_tile_lm<2, T>(Q + lm_off + half * 2048, lane, a);
-        else store_tile<2, T, 128>(Q + tile_off + 64 * half, nvalid, lane, a, scr);
-    }
-    LFT_STAMP(9);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        f32x16 a[2];
-        zero_acc<2>(a);
-        linear_ring<2, 8, T>(ring, nf, a);
         if constexpr (QKVLM) store_tile_lm<2, T>(K + lm_off + half * 2048, lane, a);
         else store_tile<2, T, 128>(K + tile_off + 64 * half, nvalid, lane, a, scr);
+    }
+    LFT_STAMP(9);
+    if constexpr (WITH_Q) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x16 a[2];
+            zero_acc<2>(a);
+            linear_ring<2, 8, T>(ring, nf, a);
+            if constexpr (QKVLM) store_tile_lm<2, T>(Q + lm_off + half * 2048, lane, a);
+            else store_tile<2, T, 128>(Q + tile_off + 64 * half, nvalid, lane, a, scr);
+        }
     }
     LFT_STAMP(11);
     publish_status(status, bad);
@@ -184,12 +188,8 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa2(const T* __restri
         f32x16 hid[2];
         zero_acc<2>(hid);
         linear_ring<2, 8, T>(ring, f, hid);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) hid[nt][i] = relu_fast(hid[nt][i]);
         Frag<T> hf[4];
-        acc_frags<2, T>(hid, hf);
+        acc_frags_relu<2>(hid, hf);
         linear_ring<4, 4, T>(ring, hf, t);
     }
     LFT_STAMP(20);
@@ -226,7 +226,7 @@ constexpr int kSpaBChunk = LFT_SPAB_CHUNK;                     // fragments per 
 constexpr int kAdTile = kAttHR * kAttHC * 64;                 // one tensor's halo tile in LDS: 8 x 36 tokens x 64 B
 constexpr int kAdPerWave = 2 * kAdTile / 1024 / 4;            // LDS-DMA pieces per wave and head pair (9)
 static_assert(2 * kAdTile == 4 * kAdPerWave * 1024, "the K and V tiles must split into whole pieces over 4 waves");
-constexpr int kSpaBLds = 4 * kAdTile + 1024;                  // two K+V buffers + LayerNorm parameters
+constexpr int kSpaBLds = 4 * kAdTile + 2048;                  // two K+V buffers + both LayerNorms' parameters (FFN: first KiB; norm: second)
 // Phase B re-uses the two K / V buffers (36 KiB each): ring slots 0 .. kSpaBSlotsA-1 in buffer A, the others in buffer B from
 // its start; the tile I/O scratch sits 16 KiB into buffer B -- behind the slots there (8-fragment chunks), or on top of the
 // LAST slot (16-fragment chunks), which is not filled before every wave has passed the first ring barrier (TOK tile loaded)
@@ -246,18 +246,60 @@ static_assert(kSpaBChunk == 8 ? kSpaBSlotsB * kSpaBChunk * 1024 <= kSpaBScratchO
 template <typename T> LFT_DEV void q_load_async(const T* p0, const T* p1, raw16& a, raw16& b) {
     asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off" : "=&v"(a), "=&v"(b) : "v"(p0), "v"(p1) : "memory");
 }
+// One 16-byte load per lane that hipcc neither counts nor waits for (see q_load_async); the caller's counted wait names the
+// destination registers before their first use.
+LFT_DEV void ld16_async(const void* p, raw16& d) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+// The same with a compile-time byte offset folded into the instruction (13-bit signed immediate: 0 .. 4095): one address
+// register pair serves four 1 KiB-spaced pieces instead of one 64-bit add per load.
+template <int OFS> LFT_DEV void ld16_async_ofs(const void* p, raw16& d) {
+    static_assert(OFS >= 0 && OFS < 4096, "global_load immediate offset");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d) : "v"(p), "n"(OFS) : "memory");
+}
+// eight pieces 1 KiB apart starting at p (two address pairs)
+LFT_DEV void ld16_async_x8(const char* p, raw16 (&d)[8]) {
+    const char* p2 = p + 4096;
+    ld16_async_ofs<0>(p, d[0]); ld16_async_ofs<1024>(p, d[1]); ld16_async_ofs<2048>(p, d[2]); ld16_async_ofs<3072>(p, d[3]);
+    ld16_async_ofs<0>(p2, d[4]); ld16_async_ofs<1024>(p2, d[5]); ld16_async_ofs<2048>(p2, d[6]); ld16_async_ofs<3072>(p2, d[7]);
+}
+// s_waitcnt vmcnt(N), then pin: no use of the eight registers moves above the wait (call once per group of eight; only the
+// first call of a sequence needs the real count, the others pass the same N -- a second identical wait costs nothing).
+template <int N> LFT_DEV void wait_vm_8(raw16 (&r)[8]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N> LFT_DEV void wait_vm_only() {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 template <int N> LFT_DEV void wait_vm_q(raw16& a, raw16& b) {          // s_waitcnt vmcnt(N); names the asm-loaded registers so no use moves above it
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Q^T rows 32 nt .. 32 nt + 31 (one head pair) of a wave's 32 tokens: eight Wq fragments (already in registers) against the
+// normalised tokens; the two 16-row halves of the accumulator are the head pair's query fragments (acc order, as K).
+template <typename T> LFT_DEV void q_head_pair(const raw16 (&wr)[8], const Frag<T> (&nf)[8], Frag<T>& q0, Frag<T>& q1) {
+    f32x16 q;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) q[i] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        Frag<T> wf;
+        wf.v = __builtin_bit_cast(typename H16<T>::v8, wr[ks]);
+        mma(wf, nf[ks], q);
+    }
+    q0 = acc_to_frag(q, 0, T());
+    q1 = acc_to_frag(q, 1, T());
+}
+
 template <typename T, bool SKIP, bool TOKLM = false, bool YLM = false>   // TOKLM: k_spa1 wrote the tokens as lane-major 32-token tiles (w % 32 == 0: a tile = 32 columns of one image row); YLM: write the output so (consumer: k_up)
 __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, const T* __restrict__ Q, const T* __restrict__ K,
                                                   const T* __restrict__ Vv, const T* __restrict__ ws, const float* __restrict__ ln,
-                                                  const T* __restrict__ skip, T* __restrict__ Y, int h, int w, unsigned* __restrict__ status) {
+                                                  const T* __restrict__ skip, T* __restrict__ Y, int h, int w, unsigned* __restrict__ status,
+                                                  const T* __restrict__ wq, const T* __restrict__ petok) {   // wq / petok: TOKLM only (Q is computed here)
     static_assert(sizeof(T) == 2, "k_spa_b is the 16-bit (bf16 / f16) part B; fp32 uses k_win_attn_lds + k_spa2");
     typedef typename H16<T>::v8 V8;
-    using Ring = WRingDeep<T, kSpaBChunk, 4, kSpaBSlots>;
+    using Ring = WRingPipe<T, kSpaBChunk, 4, kSpaBSlots, 176>;        // weight fragments double-buffered in registers across the chunk barrier
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const bufA = smem;                                          // each buffer: K tile, then V tile, of one head pair
     char* const bufB = smem + 2 * kAdTile;
@@ -308,17 +350,72 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
 #pragma unroll
         for (int i = 0; i < kAdPerWave; ++i) glds16_asm(dsrc + dofs[i] + hg * kDmaPair, buf + ddst + i * 1024);
     };
-    // Pipeline (VM operations retire in issue order):  D0 D1 Q0 | it0: wait(0) .. Q1 D2 | it1: wait(9) .. Q2 D3 |
+    // Pipeline (VM operations retire in issue order), row-major form:  D0 D1 Q0 | it0: wait(0) .. Q1 D2 | it1: wait(9) .. Q2 D3 |
     // it2: wait(9) .. Q3 R0-3 | it3: wait(8) .. R4 | phase B.   Dn = the 9 DMA pieces of head pair n, Qn = its two query
     // loads, Rc = ring chunk c (2 pieces per wave).  The wait at the top of iteration n leaves only the group issued last
     // in flight, so Dn and Qn have landed; a buffer is re-filled right after the barrier that ends its head pair.  Q0 is
     // issued last in the prologue: between an asm load and its wait the compiler must have no reason to touch the
     // destination registers (it does not know they are pending).
-    const raw16 lnv = params_load(ln + 256, 256);                     // feed_forward.0.{weight,bias}: stored to LDS after the first wait below
-    stage(0, bufA);
-    stage(1, bufB);
+    // Lane-major form (TOKLM): there are no query loads -- Q is COMPUTED in the prologue (below) -- and the iterations' waits
+    // are the same counts without them:  [tok pe Wq01 D0 D1] wait(34) LN | wait(26) Q0 Wq2 | wait(26) Q1 Wq3 | wait(8) Q2 |
+    // wait(0) Q3 | it0 .. D2 | it1: wait(9) .. D3 | it2: wait(9) .. R0-3 | it3: wait(8) ..
+    unsigned bad = 0;                                                 // non-finite activation seen (layernorm_acc; published at the end)
+    Frag<T> qfr[8];                                                   // TOKLM: this block's queries, all 8 heads, acc order
+    raw16 lnv;                                                        // feed_forward.0.{weight,bias}, to LDS after the first wait
+    if constexpr (TOKLM) {
+        // Q = LN(tok + PEtok) Wq^T for this wave's 32 tokens (reference LFT.py:181-184), from the token tile k_spa1 wrote
+        // (16-bit) -- k_spa1 no longer writes Q and this kernel no longer reads it: one [N, 128] tensor less each way.  All
+        // loads are inline-asm loads (the compiler neither counts nor drains them) under counted waits; Wq streams through
+        // two sets of eight fragment registers, 16 KB from L2 per wave and set.
+        raw16 lnv1, tokr[8], per[8], wqa[8], wqb[8];
+        const int ty_ = min(qy, h - 1);
+        const int lane_piece = (32 * hh + bxl + (r & 7)) * 8;            // this lane's 16-byte piece inside a k-step of a lane-major tile
+        const char* tsrc = reinterpret_cast<const char*>(TOK + (img0 + (long long)ty_ * w + x0) * 128 + lane_piece);
+        const char* psrc = reinterpret_cast<const char*>(petok + ((long long)ty_ * w + x0) * 128 + lane_piece);
+        const char* wsrc = reinterpret_cast<const char*>(wq) + lane * 16;
+        const int pi = min((int)threadIdx.x * 4, 252);                   // as params_load: threads beyond 64 re-read the last piece
+        ld16_async(ln + pi, lnv1);                                       // norm.{weight,bias}
+        ld16_async(ln + 256 + pi, lnv);
+        ld16_async_x8(tsrc, tokr);
+        ld16_async_x8(psrc, per);
+        ld16_async_x8(wsrc, wqa);                                         // head pair 0: fragments (nt = 0, ks = 0..7)
+        ld16_async_x8(wsrc + 8 * 1024, wqb);                              // head pair 1
+        stage(0, bufA);
+        stage(1, bufB);
+        // in flight: 2 + 16 + 16 + 18 = 52.  Tokens, position tokens and LayerNorm parameters first:
+        wait_vm_8<16 + 2 * kAdPerWave>(tokr);
+        wait_vm_8<16 + 2 * kAdPerWave>(per);
+        asm volatile("" : "+v"(lnv), "+v"(lnv1));
+        params_store(lds_ln, 256, lnv);
+        params_store(lds_ln + 256, 256, lnv1);
+        wg_barrier_keep_vm();                                            // both parameter sets published
+        f32x16 n[4];
+#pragma unroll
+        for (int kidx = 0; kidx < 8; ++kidx) {
+            const V8 vt = __builtin_bit_cast(V8, tokr[kidx]), vp = __builtin_bit_cast(V8, per[kidx]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) n[kidx >> 1][8 * (kidx & 1) + j] = (float)vt[j] + (float)vp[j];
+        }
+        layernorm_acc<4, true>(n, lds_ln + 256, lds_ln + 256 + 128, hh, bad);
+        Frag<T> nf[8];
+        acc_frags<4, T>(n, nf);
+        wait_vm_8<8 + 2 * kAdPerWave>(wqa);                              // younger: Wq set b, D0, D1
+        q_head_pair<T>(wqa, nf, qfr[0], qfr[1]);
+        ld16_async_x8(wsrc + 16 * 1024, wqa);                             // head pair 2
+        wait_vm_8<2 * kAdPerWave + 8>(wqb);                              // younger: D0, D1, the new set a
+        q_head_pair<T>(wqb, nf, qfr[2], qfr[3]);
+        ld16_async_x8(wsrc + 24 * 1024, wqb);                             // head pair 3
+        wait_vm_8<8>(wqa);                                               // D0 and D1 are older: landed as well
+        q_head_pair<T>(wqa, nf, qfr[4], qfr[5]);
+        wait_vm_8<0>(wqb);
+        q_head_pair<T>(wqb, nf, qfr[6], qfr[7]);
+    } else {
+        lnv = params_load(ln + 256, 256);
+        stage(0, bufA);
+        stage(1, bufB);
+    }
     Ring ring;
-    ring.setup(ws, smem, 176, kSpaBSlotsA, 2 * kAdTile - kSpaBSlotsA * kSpaBChunk * 1024);
+    ring.setup(ws, smem, kSpaBSlotsA, 2 * kAdTile - kSpaBSlotsA * kSpaBChunk * 1024);
     // this wave's block of tokens in memory (clamped origin: readable even when the block lies outside the image)
     BlkRows rows;
     rows.nrow = max(0, min(4, h - y0)); rows.ncol = max(0, min(8, w - (x0 + bxl)));
@@ -374,19 +471,25 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
     const int vb1 = vb0 + 24 * 64 * hh;
     LFT_STAMP(17);
     raw16 qa, qb;
-    q_load_async(qptr, qptr + kQHead, qa, qb);
+    if constexpr (!TOKLM) q_load_async(qptr, qptr + kQHead, qa, qb);
     Frag<T> of[8];                                                    // attention output of all 8 heads: out_proj's B operand, acc order
 #pragma unroll                        // of[] needs compile-time indices (a runtime index would put it in scratch)
     for (int hg = 0; hg < 4; ++hg) {
         char* const buf = (hg & 1) ? bufB : bufA;
-        if (hg == 0) { wait_vm_q<0>(qa, qb); params_store(lds_ln, 256, lnv); }
-        else if (hg < 3) wait_vm_q<kAdPerWave>(qa, qb);
-        else wait_vm_q<kSpaBSlotsA * Ring::PIECES_PER_WAVE>(qa, qb);
+        if constexpr (TOKLM) {
+            if (hg == 0) wait_vm_only<0>();                                    // (drained by the last query tile already)
+            else if (hg < 3) wait_vm_only<kAdPerWave>();
+            else wait_vm_only<kSpaBSlotsA * Ring::PIECES_PER_WAVE>();
+        } else {
+            if (hg == 0) { wait_vm_q<0>(qa, qb); params_store(lds_ln, 256, lnv); }
+            else if (hg < 3) wait_vm_q<kAdPerWave>(qa, qb);
+            else wait_vm_q<kSpaBSlotsA * Ring::PIECES_PER_WAVE>(qa, qb);
+        }
         wg_barrier_keep_vm();                                              // everybody's pieces of this head pair have landed
         LFT_STAMP(18 + 2 * hg);
         Frag<T> qf[2];
-        qf[0].v = __builtin_bit_cast(V8, qa);
-        qf[1].v = __builtin_bit_cast(V8, qb);
+        if constexpr (TOKLM) { qf[0] = qfr[2 * hg]; qf[1] = qfr[2 * hg + 1]; }
+        else { qf[0].v = __builtin_bit_cast(V8, qa); qf[1].v = __builtin_bit_cast(V8, qb); }
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl) {
             f32x16 S[3], o;
@@ -438,14 +541,16 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
         }
         LFT_STAMP(19 + 2 * hg);
         wg_barrier_keep_vm();                                              // every wave is done reading this buffer
-        if (hg < 3) q_load_async(qptr + kQPair * (hg + 1), qptr + kQPair * (hg + 1) + kQHead, qa, qb);
+        if constexpr (!TOKLM) {
+            if (hg < 3) q_load_async(qptr + kQPair * (hg + 1), qptr + kQPair * (hg + 1) + kQHead, qa, qb);
+        }
         if (hg < 2) stage(hg + 2, buf);
         else if (hg == 2) {                                                // buffer A now belongs to the weight ring
 #pragma unroll
             for (int c = 0; c < kSpaBSlotsA; ++c) ring.issue(c);
         } else {                                                           // ... and so does buffer B
 #pragma unroll
-            for (int c = kSpaBSlotsA; c < kSpaBSlots - 1; ++c) ring.issue(c);
+            for (int c = kSpaBSlotsA; c < kSpaBSlots; ++c) ring.issue(c);
         }
     }
     char* scr = bufB + kSpaBScratchOfs + wave * TileIO<4, T>::BYTES;
@@ -467,32 +572,32 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
         load_tile_map<4, T>(TOK + tok0 * 128, rt, lane, t, scr);
     }
     LFT_STAMP(26);
-    linear_ring<4, 8, T>(ring, of, t);                                // t = tok + O Wo^T
+    ring.start();
+    linear_ring_at<0, 4, 8>(ring, of, t);                             // t = tok + O Wo^T
     LFT_STAMP(27);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) n[nt] = t[nt];
-    unsigned bad = 0;
     layernorm_acc<4, true>(n, lds_ln, lds_ln + 128, hh, bad);                  // t carries whatever overflowed in tok / Q / K / V / the attention
     Frag<T> f[8];
     acc_frags<4, T>(n, f);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    auto ffn_chunk = [&](auto cc) __attribute__((always_inline)) {                                   // hidden units 64 c .. 64 c + 63: stream positions 32 + 32 c ..
+        constexpr int C = decltype(cc)::value;
         f32x16 hid[2];
         zero_acc<2>(hid);
-        linear_ring<2, 8, T>(ring, f, hid);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) hid[nt][i] = relu_fast(hid[nt][i]);
+        linear_ring_at<32 + 32 * C, 2, 8>(ring, f, hid);
         Frag<T> hf[4];
-        acc_frags<2, T>(hid, hf);
-        linear_ring<4, 4, T>(ring, hf, t);
-    }
+        acc_frags_relu<2>(hid, hf);
+        linear_ring_at<32 + 32 * C + 16, 4, 4>(ring, hf, t);
+    };
+    ffn_chunk(std::integral_constant<int, 0>());
+    ffn_chunk(std::integral_constant<int, 1>());
+    ffn_chunk(std::integral_constant<int, 2>());
+    ffn_chunk(std::integral_constant<int, 3>());
     LFT_STAMP(28);
     acc_frags<4, T>(t, f);
     f32x16 y[2];
     zero_acc<2>(y);
-    linear_ring<2, 8, T>(ring, f, y);
+    linear_ring_at<160, 2, 8>(ring, f, y);
     LFT_STAMP(29);
     BlkRows ry = rows; ry.img_row_bytes = w * 128; ry.tok_bytes = 128;
     if (SKIP) {

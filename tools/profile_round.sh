@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU box: rocprofv3 evidence for the current build -> gpurun_out/prof_<tag>/ (copy the summaries into profiles/ afterwards).
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r03
 # Kernel trace and the PMC passes are separate runs (a --pmc run never carries a trace domain); the program follows `--` directly.
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
