@@ -361,13 +361,14 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
     // wait(0) Q3 | it0 .. D2 | it1: wait(9) .. D3 | it2: wait(9) .. R0-3 | it3: wait(8) ..
     unsigned bad = 0;                                                 // non-finite activation seen (layernorm_acc; published at the end)
     Frag<T> qfr[8];                                                   // TOKLM: this block's queries, all 8 heads, acc order
+    raw16 tokr[8];                                                    // TOKLM: this lane's token pieces, kept packed for the residual of phase B
     raw16 lnv;                                                        // feed_forward.0.{weight,bias}, to LDS after the first wait
     if constexpr (TOKLM) {
         // Q = LN(tok + PEtok) Wq^T for this wave's 32 tokens (reference LFT.py:181-184), from the token tile k_spa1 wrote
         // (16-bit) -- k_spa1 no longer writes Q and this kernel no longer reads it: one [N, 128] tensor less each way.  All
         // loads are inline-asm loads (the compiler neither counts nor drains them) under counted waits; Wq streams through
         // two sets of eight fragment registers, 16 KB from L2 per wave and set.
-        raw16 lnv1, tokr[8], per[8], wqa[8], wqb[8];
+        raw16 lnv1, per[8], wqa[8], wqb[8];
         const int ty_ = min(qy, h - 1);
         const int lane_piece = (32 * hh + bxl + (r & 7)) * 8;            // this lane's 16-byte piece inside a k-step of a lane-major tile
         const char* tsrc = reinterpret_cast<const char*>(TOK + (img0 + (long long)ty_ * w + x0) * 128 + lane_piece);
@@ -557,13 +558,12 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
     f32x16 t[4], n[4];
     if constexpr (TOKLM) {
         // Row rr of this wave's 8 x 4 block = lanes 8 wave .. 8 wave + 7 of the lane-major tile of image row y0 + rr: the 16-byte
-        // piece [k-step][32 hh + column] holds exactly registers 8k .. 8k+7 of this lane's accumulator tile (load_tile_lm),
-        // so the token tile arrives with eight 16-byte loads per lane and no LDS transposition.
-        const int ty_ = min(y0 + (r >> 3), h - 1);
-        const T* src = TOK + (img0 + (long long)ty_ * w + x0) * 128 + (32 * hh + bxl + (r & 7)) * 8;
+        // piece [k-step][32 hh + column] holds exactly registers 8k .. 8k+7 of this lane's accumulator tile (load_tile_lm).
+        // The pieces were loaded for the queries in the prologue and kept packed (32 registers) through the attention phase:
+        // a second read of the token tile would come from beyond the L2 again (26 MB per launch by the PMC counters).
 #pragma unroll
         for (int kidx = 0; kidx < 8; ++kidx) {
-            const V8 v = __builtin_bit_cast(V8, load_raw16(reinterpret_cast<const char*>(src + kidx * 512)));
+            const V8 v = __builtin_bit_cast(V8, tokr[kidx]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) t[kidx >> 1][8 * (kidx & 1) + j] = (float)v[j];
         }
