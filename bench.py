@@ -260,10 +260,34 @@ def error_figures(out, ref) -> dict:
                                                    "pixels": int(m.sum())}}
 
 
-def train_object(dev, math: str):
+def train_gemm_work(s: int) -> dict:
+    """Algorithmic work per token of the two GEMM kernel families of the training step, from the step's call list
+    (lft_train_host.cuh: train_forward / train_backward).  k_lin = every Linear / conv forward and every input gradient:
+    reads X (Cin floats; a 3x3 conv reads each input token once algorithmically), optionally a residual R or an activation
+    mask M (Cout floats each), writes Y (Cout floats).  k_wgrad = every weight gradient dW = dY^T X: reads dY and X."""
+    ss = s * s
+    gt32 = 32 * (((s + 2) * (s + 2) + 31) // 32)
+    lin, wg = [], []                                   # (Cin, Cout, taps, extra Cout-sized reads)
+    lin += [(64, 64, 9, 0)] * 3                                                      # conv_init forward
+    for _ in range(4):
+        lin += [(64, 128, 1, 0), (64, 64, 1, 0), (64, 64, 1, 1), (64, 128, 1, 0), (128, 64, 1, 1)]            # ang: QK, V, out(+x), FF1, FF2(+t1)
+        lin += [(64, 128, 9, 0), (128, 256, 1, 0), (128, 128, 1, 0), (128, 128, 1, 1), (128, 256, 1, 0), (256, 128, 1, 1), (128, 64, 1, 0)]   # spa
+        # backward, spa then ang (input gradients)
+        lin += [(64, 128, 1, 0), (128, 256, 1, 1), (256, 128, 1, 0), (128, 128, 1, 0), (128, 128, 1, 1), (256, 128, 1, 0), (128, 64, 9, 0)]
+        lin += [(64, 128, 1, 1), (128, 64, 1, 0), (64, 64, 1, 0), (64, 64, 1, 1), (128, 64, 1, 0)]
+        wg += [(64, 128, 1), (128, 256, 1), (256, 128, 1), (128, 128, 1), (128, 128, 1), (256, 128, 1), (128, 64, 9)]           # spa weights
+        wg += [(64, 128, 1), (128, 64, 1), (64, 64, 1), (64, 64, 1), (128, 64, 1)]                                               # ang weights
+    lin += [(64, 64 * ss, 1, 0), (64 * ss, gt32, 1, 0), (gt32, 64 * ss, 1, 1), (64 * ss, 64, 1, 0)]          # up-sampler fwd (2) + bwd (2)
+    lin += [(64, 64, 9, 1)] * 3                                                      # conv_init backward
+    wg += [(gt32, 64 * ss, 1), (64 * ss, 64, 1)] + [(64, 64, 9)] * 3
+    return {"k_lin": {"bytes": sum(4 * (ci + co + x * co) for ci, co, _, x in lin), "flops": sum(2 * ci * co * t for ci, co, t, _ in lin), "calls": len(lin)},
+            "k_wgrad": {"bytes": sum(4 * (a + b) for a, b, _ in wg), "flops": sum(2 * a * b * t for a, b, t in wg), "calls": len(wg)}}
+
+
+def train_object(dev, math: str, with_roofline: bool = False):
     """BASELINE configs[2] shape on this GPU: A5, 2x, 32x32 LR, batch 8, fp32 tape, Adam (reference train.py:77-83)."""
     import numpy as np
-    from lft_amd import train as T
+    from lft_amd import _lib, train as T
     from lft_amd.params import deterministic_state, synthetic_lr
     from model import LFT
     A3, S3, B3 = 5, 2, 8
@@ -287,6 +311,48 @@ def train_object(dev, math: str):
            "math": math, "ms_per_step": dt / n * 1e3, "patches_per_s": B3 * n / dt, "steps": n,
            "algorithmic_tflops": tflops, "fp32_peak_tflops": PEAK_TFLOPS["fp32"], "frac_of_fp32_peak": tflops / PEAK_TFLOPS["fp32"],
            "tape_bytes": T.tape_bytes(B3, A3, 32, 32, S3), "loss": float(loss)}
+    if with_roofline:
+        # The step's dominant kernel family, timed live: one forward + backward on one stream with a HIP event after every kernel
+        # (lft_train_step_profiled), the family's algorithmic bytes / FLOPs from the step's call list.
+        ntok = B3 * A3 * A3 * 32 * 32
+        tape = torch.empty(T.tape_bytes(B3, A3, 32, 32, S3), dtype=torch.uint8, device=dev)
+        o = torch.empty((B3, 1, A3 * 32 * S3, A3 * 32 * S3), device=dev)
+        g = torch.empty(T.grad_floats(S3), device=dev)
+        dout = torch.full_like(o, 1.0 / o.numel())
+        n_max = 1024
+        ms = (ctypes.c_float * n_max)()
+        names = (ctypes.c_char_p * n_max)()
+        cnt = ctypes.c_int(0)
+        acc = {}
+        reps = 3
+        for _ in range(reps):
+            _lib.check(_lib.lib().lft_train_step_profiled(T._ptr_array(ts.params), len(ts.params), lr.data_ptr(), o.data_ptr(), tape.data_ptr(), dout.data_ptr(),
+                                                          g.data_ptr(), B3, A3, 32, 32, S3, T.MATH[math], torch.cuda.current_stream().cuda_stream,
+                                                          n_max, ms, names, ctypes.byref(cnt)), "lft_train_step_profiled")
+            for i in range(cnt.value):
+                k = names[i].decode()
+                t, c = acc.get(k, (0.0, 0))
+                acc[k] = (t + ms[i], c + 1)
+        fam = {k: {"ms_per_step": t / reps, "launches_per_step": c // reps} for k, (t, c) in acc.items()}
+        dom = max(fam, key=lambda k: fam[k]["ms_per_step"])
+        work = train_gemm_work(S3).get(dom)
+        roof = {"kernel": dom, "ms_per_step_all_launches": fam[dom]["ms_per_step"], "launches_per_step": fam[dom]["launches_per_step"],
+                "method": "HIP event after every kernel of one forward + backward on one stream (lft_train_step_profiled), mean of 3",
+                "gpu_ms_per_step_sum": sum(v["ms_per_step"] for v in fam.values()),
+                "families_ms": {k: round(v["ms_per_step"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])}}
+        if work:
+            gbyte, gflop = work["bytes"] * ntok / 1e9, work["flops"] * ntok / 1e9
+            t_ms = fam[dom]["ms_per_step"]
+            peak = PEAK_TFLOPS["fp32"] if math == "fp32" else PEAK_TFLOPS["bf16"] / 3.0          # split-bf16: three bf16 MFMAs per product
+            t_mfma, t_hbm = gflop / (peak * 1e3), gbyte / HBM_PEAK_GBS
+            if t_mfma >= t_hbm:
+                roof.update(bound="mfma", achieved=gflop / t_ms, peak=peak, unit="TFLOP/s", frac=gflop / t_ms / peak)
+            else:
+                roof.update(bound="hbm", achieved=gbyte / (t_ms * 1e-3), peak=HBM_PEAK_GBS, unit="GB/s", frac=gbyte / (t_ms * 1e-3) / HBM_PEAK_GBS)
+            roof["algorithmic_per_step"] = {"gbyte": gbyte, "gflop": gflop, "calls": work["calls"]}
+            roof["traffic"] = None                       # PMC passes of the training step: profiles/r03_train_* (not read back here)
+        out["roofline"] = roof
+        del tape, o, g
     del ts, net
     torch.cuda.empty_cache()
     return out
@@ -552,8 +618,9 @@ def main():
             result["parity_path"], outs = parity_path(args, dev, lr, net)
         if extras and args.config == "cfg2":
             note("timing the training step (BASELINE configs[2] shape) ...")
-            result["train"] = train_object(dev, "fp32")
-            result["train"]["bf16x3"] = {k: v for k, v in train_object(dev, "bf16x3").items() if k in ("ms_per_step", "patches_per_s", "algorithmic_tflops")}
+            result["train"] = train_object(dev, "fp32", with_roofline=True)
+            result["train"]["bf16x3"] = {k: v for k, v in train_object(dev, "bf16x3", with_roofline=True).items()
+                                          if k in ("ms_per_step", "patches_per_s", "algorithmic_tflops", "roofline")}
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle on host cores ...")
             result["cpu_baseline"], ref = cpu_baseline(args.cpu_seconds, lr[:1].cpu())

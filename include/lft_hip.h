@@ -161,6 +161,12 @@ int lft_train_backward_buckets(const float* const* params, int nparams, const fl
                                int B, int A, int h, int w, int s, int math, void* stream, void* side_stream,
                                lft_bucket_fn on_bucket, void* user);
 int lft_train_grad_bucket(int s, int bucket, size_t* first_float, size_t* n_floats);
+/* Profiling aid, NOT for the hot path (bench.py's `train.roofline`): lft_train_forward + lft_train_backward on ONE stream with a HIP
+ * event after every kernel; SYNCHRONISES the stream and returns per-kernel milliseconds in launch order (host arrays of max_records
+ * entries, names are static strings; a step has about 450 launches). */
+int lft_train_step_profiled(const float* const* params, int nparams, const float* lr, float* out, void* tape, const float* dout, float* grads,
+                            int B, int A, int h, int w, int s, int math, void* stream,
+                            int max_records, float* ms_out, const char** names_out, int* n_out);
 /* get_loss (reference LFT.py:269-277, torch.nn.L1Loss): *loss = mean |sr - hr|; if dsr != NULL also
  * dsr = gscale * sign(sr - hr) (gscale = 1/n for d loss / d sr).  scratch1024: 1024 floats of device scratch. */
 int lft_l1_loss(const float* sr, const float* hr, long long n, float* dsr, float gscale, float* loss, float* scratch1024, void* stream);

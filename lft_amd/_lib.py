@@ -66,14 +66,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
-# Flags of both translation units (lft_api.hip compiles as LFT_TU=1, the inference side, and LFT_TU=2, the training step).
+# Flags of both translation units (lft_api.hip compiles as LFT_TU=1, the inference side, and LFT_TU=2, the training step: two
+# units only so that they build in parallel).
 # -amdgpu-schedule-relaxed-occupancy: the kernels' occupancy is set by their LDS footprint and launch bounds, so the
 #   scheduler may spend registers on a better instruction order (+1.2 %, k_spa1 43 -> 41 us event-timed); no arithmetic changes.
-# -fno-slp-vectorize (inference unit only): hipcc's SLP pass packs neighbouring scalar f32 operations into v_pk_*_f32, which
-#   issue slower beside MFMAs than the two scalar instructions (+1.4 %).  The training unit keeps the default: SLP also decides
-#   which of its fp32 multiply-adds are contracted, and the step's last-bit behaviour is pinned by the gradient fixtures.
+# -fno-slp-vectorize: hipcc's SLP pass packs neighbouring scalar f32 operations into v_pk_*_f32, which issue slower beside
+#   MFMAs than the two scalar instructions (+1.4 % on the inference bench).  Until round 3 the training unit kept the default
+#   because the pass also decides which fp32 multiply-adds get contracted, enough to flip a ReLU unit in the screened-seed
+#   gradient test; the kink-aligned gradient tests (tests/test_gpu_train.py) pass with and without the flag, so the flags
+#   are no longer pinned by a test and both units use the same set.
 COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-schedule-relaxed-occupancy=true", "-fPIC"]
-UNIT_FLAGS = {1: ["-fno-slp-vectorize"], 2: []}
+UNIT_FLAGS = {1: ["-fno-slp-vectorize"], 2: ["-fno-slp-vectorize"]}
 
 
 def _objects(lib_path):
@@ -131,6 +134,8 @@ _SIGS = {
     "lft_train_backward_buckets": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                            c_void_p, c_void_p, c_void_p, c_void_p]),
     "lft_train_grad_bucket": (c_int, [c_int, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
+    "lft_train_step_profiled": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_int, POINTER(c_float), POINTER(c_char_p), POINTER(c_int)]),
     "lft_l1_loss": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "lft_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_void_p]),
     "lft_view_metrics_scratch_bytes": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),

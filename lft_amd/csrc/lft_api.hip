@@ -874,6 +874,34 @@ int lft_train_backward_buckets(const float* const* params, int nparams, const fl
     return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, math, static_cast<hipStream_t>(stream),
                           static_cast<hipStream_t>(side_stream), on_bucket, user);
 }
+int lft_train_step_profiled(const float* const* params, int nparams, const float* lr, float* out, void* tape, const float* dout, float* grads,
+                            int B, int A, int h, int w, int s, int math, void* stream, int max_records, float* ms_out, const char** names_out, int* n_out) {
+    Dims d; int rc;
+    if (!params || !lr || !out || !tape || !dout || !grads || !ms_out || !names_out || !n_out) return fail(LFT_ERR_ARG, "null pointer");
+    if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
+    if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
+    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32 or LFT_MATH_BF16X3, got %d", math);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    g_prof.on = true; g_prof.st = st; g_prof.ev.clear(); g_prof.names.clear();
+    prof_mark("start");
+    rc = train_forward(params, lr, out, static_cast<float*>(tape), d, math, st);
+    if (!rc) rc = train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, math, st, nullptr);    // one stream: every kernel between two events
+    g_prof.on = false;
+    hipError_t e = hipStreamSynchronize(st);
+    int n = 0;
+    for (size_t i = 1; i < g_prof.ev.size() && n < max_records; ++i, ++n) {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, g_prof.ev[i - 1], g_prof.ev[i]);
+        ms_out[n] = ms;
+        names_out[n] = g_prof.names[i];
+    }
+    for (hipEvent_t ev : g_prof.ev) (void)hipEventDestroy(ev);
+    g_prof.ev.clear(); g_prof.names.clear();
+    *n_out = n;
+    if (rc) return rc;
+    if (e != hipSuccess) return fail((int)e, "hipStreamSynchronize: %s", hipGetErrorString(e));
+    return 0;
+}
 int lft_train_grad_bucket(int s, int bucket, size_t* first_float, size_t* n_floats) {
     if (!first_float || !n_floats) return fail(LFT_ERR_ARG, "null pointer");
     if (s != 2 && s != 4) return fail(LFT_ERR_SHAPE, "scale factor must be 2 or 4, got %d", s);

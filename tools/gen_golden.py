@@ -246,12 +246,6 @@ def main():
         train_case(ref, "train_a3_s2_b2_6x6", 3, 2, 2, 6, 6)
         train_case(ref, "train_a2_s4_b1_8x5", 2, 4, 1, 8, 5)
         return
-    if "--train-large-only" in sys.argv:
-        # 12 800 tokens, input seed 6: screened so that the gradients are well conditioned in fp32 -- autograd in fp32 and in
-        # fp64 agree to 1.9e-4 of every tensor's scale on this input (seeds 0..5, 7 have a unit within fp32 rounding of a ReLU
-        # kink: 3.5e-4 .. 9e-4 between fp32 and fp64 themselves), so an independent implementation can be held to 1e-3 outright
-        train_case(ref, "train_a5_s2_b2_16x16", 5, 2, 2, 16, 16, iseed=6, adam_steps=1)
-        return
     if "--train-kink-only" in sys.argv:
         # the same shape on UNSCREENED input seeds, with the reference's branch decisions (tests/test_gpu_train.py:
         # test_gradients_on_unscreened_inputs_with_aligned_kinks)
@@ -273,7 +267,6 @@ def main():
     run_case(ref, "cfg1_a5_s2_b1_32x32", 5, 2, 1, 32, 32, flavor="default")   # BASELINE configs[0]
     train_case(ref, "train_a3_s2_b2_6x6", 3, 2, 2, 6, 6)
     train_case(ref, "train_a2_s4_b1_8x5", 2, 4, 1, 8, 5)
-    train_case(ref, "train_a5_s2_b2_16x16", 5, 2, 2, 16, 16, iseed=6, adam_steps=1)
     run_case(ref, "cfg2_a5_s4_b1_32x32", 5, 4, 1, 32, 32, flavor="default")   # one patch of configs[1]
     for iseed in (0, 1, 2):
         train_kink_case(ref, f"train_kink_a5_s2_b2_16x16_seed{iseed}", 5, 2, 2, 16, 16, iseed=iseed)
