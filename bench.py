@@ -518,7 +518,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # LFT_DP_FORCE_COLLECTIVES=1 under a launcher with ONE rank: initialise RCCL anyway, so that a one-GPU box runs the
+    # collectives of the multi-rank path end to end (loop-back; its timings say nothing about scaling)
+    forced = world == 1 and os.environ.get("LFT_DP_FORCE_COLLECTIVES", "0") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or forced:
         import torch.distributed as dist
         if rehearsal:
             dist.init_process_group("gloo")
