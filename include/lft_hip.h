@@ -132,9 +132,9 @@ int lft_scene_integrate(const float* sr_patches, float* sr_scene, int A, int h0,
  * lft_train_backward: dout [B,1,A*h*s,A*w*s] -> grads = ONE flat fp32 buffer (lft_train_grad_floats) holding the 78
  *                     parameter gradients back to back in state_dict order, fully overwritten (not accumulated).
  *                     A data-parallel job all-reduces this one buffer.  No gradient flows to lr.
- *                     side_stream (may be NULL): a second stream of the caller's on which the weight-gradient kernels run
- *                     beside the data-gradient chain; it is forked from and joined back into `stream` with events, so the
- *                     call stays stream-ordered on `stream` (and graph-capturable).
+ *                     side_stream: accepted for ABI compatibility and ignored since ABI 4 -- the gradient tensors of the pass live
+ *                     in an arena of the tape and are re-used as they die, which needs every kernel on ONE stream (round 2 ran
+ *                     the weight-gradient kernels on it: +3 % speed for twice the tape).
  * lft_train_tape_offset: float offset of a saved activation inside the tape, for tests ("feat", "ang0.y", "spa2.tok", ...). */
 int lft_train_tape_bytes(int B, int A, int h, int w, int s, size_t* out_bytes);
 int lft_train_grad_floats(int s, size_t* out_floats);

@@ -106,7 +106,7 @@ struct TrainLayout {
     SpaTape spa[kLayers];
     size_t body, act, skip;                      // act = lrelu(U) [N, 64 s^2]; skip = bicubic(lr)
     // backward scratch
-    size_t bwd, bwd_floats, gu, stats, part, pgb;       // bwd: gradient tensors of the backward pass, one fresh buffer each
+    size_t bwd, bwd_floats, gu, stats, part, pgb;       // bwd: arena of the backward pass's gradient tensors (re-used as they die)
     size_t part_floats, total;                   // total in floats
 };
 constexpr int kWgChunks = 128;                   // token chunks (= workgroups of 4 waves) of a weight-gradient launch
@@ -114,6 +114,7 @@ constexpr int kLnBlocks = 512;                   // workgroups (= partial rows) 
 constexpr int kTailWaves = 2048;                 // waves of the up-sampler / conv0 weight-gradient kernels
 inline int wg_chunks(long long N) { return (int)std::min<long long>(kWgChunks, std::max<long long>(4, N / 512)); }   // workgroups of 4 waves, >= 128 tokens per wave
 
+size_t bwd_arena_peak(const Dims& d);
 TrainLayout train_layout(const Dims& d) {
     TrainLayout T;
     size_t o = 0;
@@ -134,17 +135,20 @@ TrainLayout train_layout(const Dims& d) {
     }
     T.body = take(n * 64); T.act = take(n * 64 * ss);
     T.skip = take((size_t)d.B * d.A * d.h * d.s * d.A * d.w * d.s);
-    // Every gradient tensor of the backward pass gets its own buffer (no reuse): the weight-gradient kernels then only
-    // depend on their producers and can run on a second stream beside the data-gradient chain.  Per token: the tail 64,
-    // per layer 1728 (SpaTrans) + 704 (AngTrans), the feature extractor 320 floats; plus the 4 position-token gradients.
-    T.bwd_floats = n * (64 + 64 + (size_t)kLayers * (1728 + 704) + 320) + (size_t)kLayers * (((size_t)d.hw * 128 + 63) & ~(size_t)63) + (size_t)64 * 64 * ss;
+    // The gradient tensors of the backward pass live in an arena and are released at their last use (train_backward: every
+    // kernel of a pass runs on ONE stream, so a buffer may be handed out again as soon as its last reader is enqueued); the
+    // arena is as large as the pass's peak live set, found by running the pass's own allocation sequence without launching
+    // anything (bwd_arena_peak).  Round 2 gave every tensor a buffer of its own (40 KB per token) so that the weight-gradient
+    // kernels could run on a second stream: that overlap bought 3 % and cost half of the tape.
+    T.bwd_floats = bwd_arena_peak(d);
     T.bwd = take(T.bwd_floats);
     T.gu = take(n * 64 * ss);
     T.stats = take(n * 8 * 3);
-    // every producer of partial sums gets its own region (one k_reduce_all launch at the end of the backward pass):
-    // weight gradients (all parameters + the position-token share of the 4 embedding weights), 16 LayerNorms, 2 tails
-    T.part_floats = (size_t)wg_chunks(d.ntok) * ((size_t)param_info(d.s).total + 64 + (size_t)64 * 64 * ss) + (size_t)4 * wg_chunks(d.hw) * 128 * 576
-                    + (size_t)16 * kLnBlocks * 256 + (size_t)2 * kTailWaves * 576;
+    // Partial sums (weight gradients per token chunk, LayerNorm rows, tails) are reduced at the end of every LAYER of the
+    // backward pass (k_reduce_all) and the region is re-used by the next one: sized for the largest -- one layer plus the
+    // up-sampler -- not for all parameters at once (round 2: 0.6 GB at B = 8).
+    T.part_floats = (size_t)wg_chunks(d.ntok) * ((size_t)param_info(d.s).total / 4 + (size_t)2 * 64 * 64 * ss + 8192) + (size_t)wg_chunks(d.hw) * 128 * 576
+                    + (size_t)4 * kLnBlocks * 256 + (size_t)2 * kTailWaves * 576;
     T.part = take(T.part_floats);
     T.pgb = 0;
     T.total = o;
@@ -184,13 +188,15 @@ struct TrainCtx {
     RedTab* red = nullptr;     // backward only: pending reductions (k_reduce_all) ...
     size_t* part_used = nullptr;   // ... and the next free float of the partial buffer
     const float* gbase = nullptr;  // flat gradient buffer (segment destinations are offsets into it)
-    hipStream_t side = nullptr;    // backward only: stream of the weight-gradient kernels (null: same stream)
+    hipStream_t side = nullptr;    // (unused since the arena: every kernel of a pass runs on `st`)
+    bool dry = false;              // sizing pass: allocation sequence only, nothing is launched
     float* F(size_t off) const { return tp + off; }
 };
 
 // Y[N][ldy cols o0..] = act(X W(view)^T) (+R).  ot0 / nOT select a block of the view's output tiles (taps == 1 only).
 int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int ldx, int flip, int act, const float* R, int ldr,
             float* Y, int ldy, long long N, const float* M = nullptr, int mact = 0) {
+    if (c.dry) return 0;
     const WView& v = c.W.v[view];
     if (nOT <= 0) nOT = v.OT;
     if ((v.taps != 1 && (ot0 || nOT != v.OT))) return fail(LFT_ERR_ARG, "run_lin: bad tile block (view %d)", view);
@@ -246,6 +252,7 @@ hipEvent_t next_event() {
 }
 // weight gradient of either: dW (+)= dY^T X  (taps = 1 or 9)
 int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, int taps, float* dW, int accumulate, long long N) {
+    if (c.dry) return 0;
     if (Co % 32 || Ci % 64) return fail(LFT_ERR_ARG, "wgrad: Co %d / Ci %d not supported", Co, Ci);
     const long long wsize = (long long)Co * Ci * taps;
     const int nch = wg_chunks(N);
@@ -312,6 +319,7 @@ int ln_fwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, 
 // out = (add ? add : 0) + dLN/du ; dgamma, dbeta written
 int ln_bwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, const float* g, const float* dY, const float* add,
            float* out, float* dgamma, float* dbeta, long long N) {
+    if (c.dry) return 0;
     const int nb = (int)std::min<long long>(kLnBlocks, (N + 15) / 16);
     const size_t poff = *c.part_used;
     *c.part_used += (size_t)nb * 2 * C;
@@ -325,11 +333,13 @@ int ln_bwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, 
     return red_push(c, poff, nb, 2 * C, 2 * C, dgamma, 0);
 }
 int act_bwd(const TrainCtx& c, const float* g, const float* y, float* out, long long n, int mode) {
+    if (c.dry) return 0;
     k_act_bwd<<<blocks_for(n / 4, 256), 256, 0, c.st>>>(g, y, out, n / 4, mode);
     LFT_LAUNCH_OK("k_act_bwd");
     return 0;
 }
 int add3(const TrainCtx& c, float* out, const float* a, const float* b, long long n) {
+    if (c.dry) return 0;
     k_add3<<<blocks_for(n / 4, 256), 256, 0, c.st>>>(out, a, b, n / 4);
     LFT_LAUNCH_OK("k_add3");
     return 0;
@@ -341,6 +351,7 @@ int add_to(const TrainCtx& c, float* a, const float* b, long long n) {
 }
 template <bool BWD>
 int ang_attn(const TrainCtx& c, const float* QK, const float* Vv, float* O, const float* dO, float* dQK, float* dV) {
+    if (c.dry) return 0;
     const int V = c.d.V, npix = c.d.B * c.d.hw;
     int rc;
     if (V <= 32) {
@@ -357,6 +368,7 @@ int ang_attn(const TrainCtx& c, const float* QK, const float* Vv, float* O, cons
 
 template <int MODE>
 int win_attn(const TrainCtx& c, const float* Q, const float* K, const float* V, float* O, const float* dO, float* dQ, float* dK, float* dV) {   // Q | K and dQ | dK: [N][256]
+    if (c.dry) return 0;
     const Dims& d = c.d;
     const unsigned tiles = (unsigned)(((d.w + kWaTX - 1) / kWaTX) * ((d.h + kWaTY - 1) / kWaTY) * d.B * d.V);
     int rc;
@@ -441,32 +453,58 @@ void grad_bucket_range(int s, int bucket, size_t* first, size_t* count) {
 }
 typedef int (*BucketFn)(void* user, int bucket, size_t first_float, size_t n_floats);
 
+// First-fit arena over the tape's backward region (floats).  Host-side bookkeeping only: the kernels of a pass run on one stream,
+// so a range may be handed out again as soon as the last kernel reading it has been ENQUEUED.
+struct BwdArena {
+    float* base = nullptr;
+    size_t cap = 0, peak = 0;
+    std::vector<std::pair<size_t, size_t>> used;     // (offset, floats), sorted by offset
+    float* get(size_t n) {
+        n = (n + 63) & ~(size_t)63;
+        size_t off = 0, i = 0;
+        for (; i < used.size(); ++i) {
+            if (used[i].first - off >= n) break;
+            off = used[i].first + used[i].second;
+        }
+        used.insert(used.begin() + (long)i, std::make_pair(off, n));
+        peak = std::max(peak, off + n);
+        return base + off;
+    }
+    void put(const float* p) {
+        const size_t off = (size_t)(p - base);
+        for (size_t i = 0; i < used.size(); ++i)
+            if (used[i].first == off) { used.erase(used.begin() + (long)i); return; }
+    }
+};
+
+// dry: the allocation sequence only (P, lr, tape, dout, G may be null) -- returns the arena's peak through *peak_out.
 int train_backward(const float* const* P, const float* lr, float* tape, const float* dout, float* G, const Dims& d, int math,
-                   hipStream_t st, hipStream_t side, BucketFn on_bucket = nullptr, void* user = nullptr) {
-    const TrainLayout T = train_layout(d);
+                   hipStream_t st, hipStream_t /*side: unused, kept for the ABI*/, BucketFn on_bucket = nullptr, void* user = nullptr,
+                   bool dry = false, size_t* peak_out = nullptr) {
+    TrainLayout Tdry{};
+    const TrainLayout T = dry ? Tdry : train_layout(d);
     const WViews WV = build_views(nullptr, d.s, nullptr);            // packed by this step's lft_train_forward
     RedTab red{};                                                    // every partial-sum producer registers a segment here
     size_t part_used = 0;
-    const TrainCtx c{d, tape, T, WV, st, math, &red, &part_used, G, side};
+    static float dummy_base[64];
+    TrainCtx c{d, dry ? dummy_base : tape, T, WV, st, math, &red, &part_used, G, nullptr};
+    c.dry = dry;
     const ParamInfo pi = param_info(d.s);
     const long long N = d.ntok;
     const int ss = d.s * d.s, nimg = d.B * d.V;
     int rc;
     auto g = [&](int idx) { return G + pi.off[idx]; };
-    size_t soff = 0;
-    auto nb = [&](int width) { float* p = c.F(T.bwd) + soff; soff += (size_t)N * width; return p; };   // fresh [N][width] gradient buffer
-    // End of a gradient bucket: the weight-gradient stream joins, the partial sums registered since the last bucket are
-    // reduced (one table-driven launch), then the caller is told -- everything enqueued before the callback belongs to the
-    // bucket, nothing after it touches the bucket's range of G.
+    BwdArena A;
+    A.base = c.F(T.bwd);
+    A.cap = dry ? (size_t)-1 : T.bwd_floats;
+    auto nb = [&](int width) { return A.get((size_t)N * width); };   // [N][width] gradient buffer; A.put() at its last use
+    // End of a gradient bucket: the partial sums registered since the last bucket are reduced (one table-driven launch) and
+    // their region is free again, then the caller is told -- everything enqueued before the callback belongs to the bucket,
+    // nothing after it touches the bucket's range of G.
     int red_done = 0;
     float* dM = nullptr;
-    auto end_bucket = [&](int bucket) -> int {
-        if (side) {
-            hipEvent_t ev = next_event();
-            if (!ev) return fail(LFT_ERR_ARG, "hipEventCreate failed");
-            LFT_HIP_OK(hipEventRecord(ev, side));
-            LFT_HIP_OK(hipStreamWaitEvent(st, ev, 0));
-        }
+    auto flush = [&]() -> int {                                      // reduce the partial sums registered so far; their region is free again
+        if (dry) { part_used = 0; return 0; }
         RedTab sub{};
         for (int i = red_done; i < red.nseg; ++i) {
             sub.s[sub.nseg] = red.s[i];
@@ -479,6 +517,12 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
             k_reduce_all<<<sub.nblk, 256, 0, st>>>(sub, c.F(T.part), G);
             LFT_LAUNCH_OK("k_reduce_all");
         }
+        part_used = 0;                                               // the next layer's partial sums overwrite these (stream order)
+        return 0;
+    };
+    auto end_bucket = [&](int bucket) -> int {
+        if (int frc = flush()) return frc;
+        if (dry) return 0;
         if (bucket == 0) {                                           // upsampling.3.weight: the reduced dM folded onto the 3x3 taps
             k_upm_fold<<<3, 256, 0, st>>>(dM, g(P_UP3), d.s);
             LFT_LAUNCH_OK("k_upm_fold");
@@ -491,19 +535,22 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
         }
         return 0;
     };
+#define TRY(x) do { if ((rc = (x))) return rc; } while (0)
     // ---- up-sampler tail (the transpose of its forward: gather, GEMM with the overlap-add matrix) ----
     float* gu = c.F(T.gu);
     const int gt = (d.gp + 31) / 32;
     float* dG = nb(32 * gt);
-    k_up_gather_bwd<<<blocks_for(N * 32 * gt, 256), 256, 0, st>>>(dout, dG, d.B, d.A, d.h, d.w, d.s, 32 * gt);
-    LFT_LAUNCH_OK("k_up_gather_bwd");
-    dM = c.F(T.bwd) + soff;                                          // [32 gt][64 s^2], folded onto upsampling.3.weight at the end of bucket 0
-    soff += (size_t)32 * gt * 64 * ss;
+    if (!dry) {
+        k_up_gather_bwd<<<blocks_for(N * 32 * gt, 256), 256, 0, st>>>(dout, dG, d.B, d.A, d.h, d.w, d.s, 32 * gt);
+        LFT_LAUNCH_OK("k_up_gather_bwd");
+    }
+    dM = A.get((size_t)32 * gt * 64 * ss);                           // [32 gt][64 s^2], folded onto upsampling.3.weight at the end of bucket 0
     TRY(wgrad(c, dG, 32 * gt, c.F(T.act), 64 * ss, 1, dM, 0, N));
     TRY(run_lin(c, VW_UPM_B, 0, 0, dG, 32 * gt, 0, 0, nullptr, 0, gu, 64 * ss, N, c.F(T.act), 2));   // dU = (M^T dG) * lrelu'(U)
+    A.put(dG);
     TRY(wgrad(c, gu, 64 * ss, c.F(T.body), 64, 1, g(P_UP0), 0, N));
-    float* gskip = nb(64);
-    TRY(lin_bwd(c, VW_UP_B, gu, nullptr, gskip, N));                 // d body = d y3 = d feat (global skip)
+    float* gskip = nb(64);                                           // d body = d y3 = d feat (global skip): lives to the end of the pass
+    TRY(lin_bwd(c, VW_UP_B, gu, nullptr, gskip, N));
     const float* dy = gskip;
     for (int l = kLayers - 1; l >= 0; --l) {
         // ================= SpaTrans backward: dy [N,64] -> dx =================
@@ -515,14 +562,17 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
             TRY(wgrad(c, dy, 64, c.F(sp.t2), 128, 1, g(pidx(l, S_LIN)), 0, N));
             float* dt2 = nb(128);
             TRY(lin_bwd(c, vw(l, SLIN_B), dy, nullptr, dt2, N));
+            if (dy != gskip) A.put(dy);
             TRY(wgrad(c, dt2, 128, c.F(sp.hdn), 256, 1, g(pidx(l, S_FF2)), 0, N));
             float* dhz = nb(256);
             TRY(lin_bwd(c, vw(l, SFF2_B), dt2, nullptr, dhz, N, c.F(sp.hdn), 1));           // d (W1 m) = d hdn * relu'()
             TRY(wgrad(c, dhz, 256, c.F(sp.m), 128, 1, g(pidx(l, S_FF1)), 0, N));
             float* dm = nb(128);
             TRY(lin_bwd(c, vw(l, SFF1_B), dhz, nullptr, dm, N));
+            A.put(dhz);
             float* dt1 = nb(128);
-            TRY(ln_bwd(c, 128, c.F(sp.t1), nullptr, 0, P[pidx(l, S_N2W)], dm, dt2, dt1, g(pidx(l, S_N2W)), g(pidx(l, S_N2B)), N));
+            TRY(ln_bwd(c, 128, c.F(sp.t1), nullptr, 0, P ? P[pidx(l, S_N2W)] : nullptr, dm, dt2, dt1, g(pidx(l, S_N2W)), g(pidx(l, S_N2B)), N));
+            A.put(dm); A.put(dt2);
             TRY(wgrad(c, dt1, 128, c.F(sp.o), 128, 1, g(pidx(l, S_OUT)), 0, N));
             float* dO = nb(128);
             TRY(lin_bwd(c, vw(l, SOUT_B), dt1, nullptr, dO, N));
@@ -530,24 +580,32 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
             float* dV = nb(128);
             TRY(win_attn<1>(c, c.F(sp.qk), c.F(sp.qk) + 128, c.F(sp.v), nullptr, dO, dqk, nullptr, nullptr));        // dQ (+ row stats)
             TRY(win_attn<2>(c, c.F(sp.qk), c.F(sp.qk) + 128, c.F(sp.v), nullptr, dO, nullptr, dqk + 128, dV));      // dK, dV
+            A.put(dO);
             TRY(wgrad(c, dV, 128, c.F(sp.tok), 128, 1, gin + 256 * 128, 0, N));
             float* dtokA = nb(128);
             TRY(lin_bwd(c, vw(l, SV_B), dV, dt1, dtokA, N));                                 // d tok = d t1 + dV Wv ...
+            A.put(dV); A.put(dt1);
             TRY(wgrad(c, dqk, 256, c.F(sp.n), 128, 1, gin, 0, N));                           // rows 0..255 of in_proj: Wq, Wk
             float* dn = nb(128);
             TRY(lin_bwd(c, vw(l, SQK_B), dqk, nullptr, dn, N));
+            A.put(dqk);
             float* du = nb(128);
-            TRY(ln_bwd(c, 128, c.F(sp.tok), c.F(sp.petok), 2, P[pidx(l, S_N1W)], dn, nullptr, du, g(pidx(l, S_N1W)), g(pidx(l, S_N1B)), N));  // d(tok+pe)
-            float* dpe = c.F(T.bwd) + soff;
-            soff += ((size_t)d.hw * 128 + 63) & ~(size_t)63;
-            k_sum_images<<<blocks_for((long long)d.hw * 128, 256), 256, 0, st>>>(du, nimg, (long long)d.hw * 128, dpe);
-            LFT_LAUNCH_OK("k_sum_images");
+            TRY(ln_bwd(c, 128, c.F(sp.tok), c.F(sp.petok), 2, P ? P[pidx(l, S_N1W)] : nullptr, dn, nullptr, du, g(pidx(l, S_N1W)), g(pidx(l, S_N1B)), N));  // d(tok+pe)
+            A.put(dn);
+            float* dpe = A.get((size_t)d.hw * 128);
+            if (!dry) {
+                k_sum_images<<<blocks_for((long long)d.hw * 128, 256), 256, 0, st>>>(du, nimg, (long long)d.hw * 128, dpe);
+                LFT_LAUNCH_OK("k_sum_images");
+            }
             float* dtok = nb(128);
             TRY(add3(c, dtok, dtokA, du, N * 128));                                          // ... + d(tok+pe)
+            A.put(dtokA); A.put(du);
             TRY(wgrad(c, dtok, 128, xin, 64, 9, g(pidx(l, S_MLP)), 0, N));
             TRY(wgrad(c, dpe, 128, c.F(T.pe_spa), 64, 9, g(pidx(l, S_MLP)), 1, d.hw));      // the position tokens are MLP(unfold(PE)) too (LFT.py:180)
+            A.put(dpe);
             dx = nb(64);
             TRY(lin_bwd(c, vw(l, MLP_B), dtok, nullptr, dx, N));
+            A.put(dtok);
         }
         // ================= AngTrans backward: dx -> dy of the layer below =================
         {
@@ -560,42 +618,55 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
             TRY(wgrad(c, dhz, 128, c.F(a.m), 64, 1, g(pidx(l, A_FF1)), 0, N));
             float* dm = nb(64);
             TRY(lin_bwd(c, vw(l, AFF1_B), dhz, nullptr, dm, N));
+            A.put(dhz);
             float* dt1 = nb(64);
-            TRY(ln_bwd(c, 64, c.F(a.t1), nullptr, 0, P[pidx(l, A_N2W)], dm, dx, dt1, g(pidx(l, A_N2W)), g(pidx(l, A_N2B)), N));
+            TRY(ln_bwd(c, 64, c.F(a.t1), nullptr, 0, P ? P[pidx(l, A_N2W)] : nullptr, dm, dx, dt1, g(pidx(l, A_N2W)), g(pidx(l, A_N2B)), N));
+            A.put(dm); A.put(dx);
             TRY(wgrad(c, dt1, 64, c.F(a.o), 64, 1, g(pidx(l, A_OUT)), 0, N));
             float* dO = nb(64);
             TRY(lin_bwd(c, vw(l, AOUT_B), dt1, nullptr, dO, N));
             float* dqk = nb(128);
             float* dV = nb(64);
             TRY(ang_attn<true>(c, c.F(a.qk), c.F(a.v), nullptr, dO, dqk, dV));
+            A.put(dO);
             TRY(wgrad(c, dV, 64, xin, 64, 1, gin + 128 * 64, 0, N));
             float* dxa = nb(64);
             TRY(lin_bwd(c, vw(l, AV_B), dV, dt1, dxa, N));                                   // d x = d t1 + dV Wv ...
+            A.put(dV); A.put(dt1);
             TRY(wgrad(c, dqk, 128, c.F(a.n), 64, 1, gin, 0, N));
             float* dn = nb(64);
             TRY(lin_bwd(c, vw(l, AQK_B), dqk, nullptr, dn, N));
+            A.put(dqk);
             float* dxo = nb(64);
-            TRY(ln_bwd(c, 64, xin, c.F(T.pe_ang), 1, P[pidx(l, A_N1W)], dn, dxa, dxo, g(pidx(l, A_N1W)), g(pidx(l, A_N1B)), N));   // ... + d LN(x + PE)
+            TRY(ln_bwd(c, 64, xin, c.F(T.pe_ang), 1, P ? P[pidx(l, A_N1W)] : nullptr, dn, dxa, dxo, g(pidx(l, A_N1W)), g(pidx(l, A_N1B)), N));   // ... + d LN(x + PE)
+            A.put(dn); A.put(dxa);
             dy = dxo;
         }
-        if (l == 2) TRY(end_bucket(0));
-        if (l == 0) TRY(end_bucket(1));
+        if (l == 2) { TRY(end_bucket(0)); A.put(dM); }
+        else if (l == 0) TRY(end_bucket(1));
+        else TRY(flush());
     }
     // ---- initial feature extractor ----
     float* dfeat = nb(64);
     TRY(add3(c, dfeat, dy, gskip, N * 64));
+    A.put(dy); A.put(gskip);
     float* dz3 = nb(64);
     TRY(act_bwd(c, dfeat, c.F(T.c3), dz3, N * 64, 2));
     TRY(wgrad(c, dz3, 64, c.F(T.c2), 64, 9, g(P_CONV + 2), 0, N));
     float* dz2 = nb(64);
     TRY(lin_bwd(c, VW_CONV_B + 2, dz3, nullptr, dz2, N, c.F(T.c2), 2));                    // d z2 = d c2 * lrelu'()
+    A.put(dz3);
     TRY(wgrad(c, dz2, 64, c.F(T.c1), 64, 9, g(P_CONV + 1), 0, N));
     float* dz1 = nb(64);
     TRY(lin_bwd(c, VW_CONV_B + 1, dz2, nullptr, dz1, N, c.F(T.c1), 2));                    // d z1 = d c1 * lrelu'()
+    A.put(dz2);
     TRY(wgrad(c, dz1, 64, c.F(T.x0), 64, 9, g(P_CONV + 0), 0, N));
     float* dx0 = nb(64);
     TRY(lin_bwd(c, VW_CONV_B + 0, dz1, dfeat, dx0, N));                                    // d x0 = d feat + conv path
-    if (soff > T.bwd_floats) return fail(LFT_ERR_ARG, "internal: backward scratch overflow (%zu > %zu)", soff, T.bwd_floats);
+    A.put(dz1); A.put(dfeat);
+    if (peak_out) *peak_out = A.peak;
+    if (dry) return 0;
+    if (A.peak > T.bwd_floats) return fail(LFT_ERR_ARG, "internal: backward arena overflow (%zu > %zu)", A.peak, T.bwd_floats);
     {
         const long long per = (N + kTailWaves - 1) / kTailWaves;
         const size_t poff = part_used;
@@ -608,4 +679,14 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
     TRY(end_bucket(2));
 #undef TRY
     return 0;
+}
+size_t bwd_arena_peak(const Dims& d) {
+    // the pass's own allocation sequence, nothing launched; cached for the last shape (every entry point computes the layout)
+    static thread_local Dims last{};
+    static thread_local size_t last_peak = 0;
+    if (last_peak && last.B == d.B && last.A == d.A && last.h == d.h && last.w == d.w && last.s == d.s) return last_peak;
+    size_t peak = 0;
+    (void)train_backward(nullptr, nullptr, nullptr, nullptr, nullptr, d, LFT_MATH_F32, nullptr, nullptr, nullptr, nullptr, true, &peak);
+    last = d; last_peak = peak;
+    return peak;
 }
