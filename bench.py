@@ -323,23 +323,28 @@ def train_object(dev, math: str, with_roofline: bool = False):
         ms = (ctypes.c_float * n_max)()
         names = (ctypes.c_char_p * n_max)()
         cnt = ctypes.c_int(0)
-        acc = {}
+        acc, shapes = {}, {}
         reps = 3
         for _ in range(reps):
             _lib.check(_lib.lib().lft_train_step_profiled(T._ptr_array(ts.params), len(ts.params), lr.data_ptr(), o.data_ptr(), tape.data_ptr(), dout.data_ptr(),
                                                           g.data_ptr(), B3, A3, 32, 32, S3, T.MATH[math], torch.cuda.current_stream().cuda_stream,
                                                           n_max, ms, names, ctypes.byref(cnt)), "lft_train_step_profiled")
             for i in range(cnt.value):
-                k = names[i].decode()
+                full = names[i].decode()                     # "k_lin:128>256 +R": family, then the call's shape
+                k = full.split(":")[0]
                 t, c = acc.get(k, (0.0, 0))
                 acc[k] = (t + ms[i], c + 1)
+                if full != k:
+                    t, c = shapes.get(full, (0.0, 0))
+                    shapes[full] = (t + ms[i], c + 1)
         fam = {k: {"ms_per_step": t / reps, "launches_per_step": c // reps} for k, (t, c) in acc.items()}
         dom = max(fam, key=lambda k: fam[k]["ms_per_step"])
         work = train_gemm_work(S3).get(dom)
         roof = {"kernel": dom, "ms_per_step_all_launches": fam[dom]["ms_per_step"], "launches_per_step": fam[dom]["launches_per_step"],
                 "method": "HIP event after every kernel of one forward + backward on one stream (lft_train_step_profiled), mean of 3",
                 "gpu_ms_per_step_sum": sum(v["ms_per_step"] for v in fam.values()),
-                "families_ms": {k: round(v["ms_per_step"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])}}
+                "families_ms": {k: round(v["ms_per_step"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+                "gemm_shapes_ms": {k: [round(t / reps, 3), c // reps] for k, (t, c) in sorted(shapes.items(), key=lambda kv: -kv[1][0])}}
         if work:
             gbyte, gflop = work["bytes"] * ntok / 1e9, work["flops"] * ntok / 1e9
             t_ms = fam[dom]["ms_per_step"]

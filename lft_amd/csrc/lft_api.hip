@@ -16,6 +16,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
+#include <set>
 #include <string>
 #include <algorithm>
 #include <utility>
@@ -62,6 +63,17 @@ struct Profiler {
     std::vector<const char*> names;
 };
 thread_local Profiler g_prof;
+// Launch name with the call's shape appended ("k_lin:128>256", profiled runs only); interned, so the pointer stays valid.
+inline const char* prof_name(const char* plain, const char* fmt, ...) {
+    if (!g_prof.on) return plain;
+    static thread_local std::set<std::string> names;
+    char buf[96];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return names.insert(buf).first->c_str();
+}
 inline void prof_mark(const char* name) {
     if (!g_prof.on) return;
     hipEvent_t e;

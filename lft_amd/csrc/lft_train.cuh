@@ -188,7 +188,7 @@ struct WgP {
 // The 4 waves of a workgroup split the chunk's tokens and add their accumulators through LDS, in a fixed order:
 // one partial image per workgroup (a quarter of the partial-sum traffic for the same number of waves in flight).
 template <int NI, bool M3, int TX>
-__global__ __launch_bounds__(256) void k_wgrad(const WgP p) {
+__global__ __launch_bounds__(256, TX == 3 ? 2 : 3) void k_wgrad(const WgP p) {
     extern __shared__ __attribute__((aligned(16))) float wred[];        // [3 waves][TX * NI tiles][16][64]
     const int lane = threadIdx.x & 63, r = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -201,28 +201,45 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgP p) {
     f32x16 acc[TX][NI];
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx) zero_acc<NI>(acc[tx]);
-    for (long long t0 = ta; t0 < tb; t0 += 16) {
+    // Addressing: wave-uniform anchors (scalar registers) + one 32-bit byte offset per lane, advanced by 16 tokens per step; the
+    // lane's image position (ys, xs) is advanced the same way -- the 64-bit token arithmetic (a division per fragment element:
+    // ~1 000 of the loop's 1 600 instructions around 12 MFMAs) happens once per wave.  Lanes outside the chunk or the image read
+    // the anchor's own row and are zeroed.
+    const int nsub = (int)max(0LL, tb - ta);
+    const int pre = TX == 3 ? p.w + 1 : 0;                              // the X anchor lies `pre` tokens before the wave's first token
+    const char* ya = reinterpret_cast<const char*>(p.dY) + (ta * p.ldy + o0) * 4;
+    const char* xa = reinterpret_cast<const char*>(p.X) + ((ta - pre) * p.ldx + i0) * 4;
+    const unsigned safe_x = ((unsigned)pre * p.ldx + r) * 4u, safe_y = r * 4u;
+    unsigned vy = ((unsigned)(8 * kh) * p.ldy + r) * 4u, vx = ((unsigned)(8 * kh + pre) * p.ldx + r) * 4u;
+    int rl = 8 * kh, ys = 0, xs = 0;
+    if constexpr (TX == 3) { const int pix = (int)((ta + 8 * kh) % hw); ys = pix / p.w; xs = pix - ys * p.w; }
+    for (int step = 0; step * 16 < nsub; ++step) {
         Frag<float> a, b[TX][NI];
+        int y = ys, x = xs;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const long long t = t0 + 8 * kh + j;
-            const bool in = t < tb;
-            const long long tc = in ? t : ta;
-            const int pix = (int)(tc % hw), y = pix / p.w, x = pix - y * p.w;
+            const bool in = rl + j < nsub;
             const bool okrow = in && (y + dy >= 0) && (y + dy < p.h);
-            const float av = p.dY[tc * p.ldy + o0 + r];
+            const float av = *reinterpret_cast<const float*>(ya + (in ? vy + (unsigned)(j * p.ldy) * 4u : safe_y));
             if (j < 4) a.lo[j] = in ? av : 0.0f; else a.hi[j - 4] = in ? av : 0.0f;
 #pragma unroll
             for (int tx = 0; tx < TX; ++tx) {
                 const int dx = TX == 3 ? tx - 1 : 0;
-                const bool ok = okrow && (x + dx >= 0) && (x + dx < p.w);
-                const float* xr = p.X + (ok ? tc + dy * p.w + dx : tc) * p.ldx + i0 + r;
+                const bool ok = TX == 3 ? okrow && (x + dx >= 0) && (x + dx < p.w) : in;
+                const float* xr = reinterpret_cast<const float*>(xa + (ok ? vx + (unsigned)((j + dy * p.w + dx) * p.ldx) * 4u : safe_x));
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const float bv = xr[32 * ni];
-                    if (j < 4) b[tx][ni].lo[j] = ok ? bv : 0.0f; else b[tx][ni].hi[j - 4] = ok ? bv : 0.0f;
+                    const float bz = TX == 3 ? (ok ? bv : 0.0f) : bv;   // plain: a row outside the chunk meets a zeroed dY element (the anchor row read instead is finite data)
+                    if (j < 4) b[tx][ni].lo[j] = bz; else b[tx][ni].hi[j - 4] = bz;
                 }
             }
+            if constexpr (TX == 3) { if (++x == p.w) { x = 0; if (++y == p.h) y = 0; } }
+        }
+        rl += 16; vy += 16u * p.ldy * 4u; vx += 16u * p.ldx * 4u;
+        if constexpr (TX == 3) {
+            xs += 16;
+            while (xs >= p.w) { xs -= p.w; if (++ys == p.h) ys = 0; }
         }
         if constexpr (M3) {
             const Frag2 a2 = split_frag(a);

@@ -216,7 +216,7 @@ int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int l
     } while (0)
     if (nt == 4) LFT_LAUNCH_LIN(4); else if (nt == 2) LFT_LAUNCH_LIN(2); else LFT_LAUNCH_LIN(1);
 #undef LFT_LAUNCH_LIN
-    LFT_LAUNCH_OK("k_lin");
+    LFT_LAUNCH_OK(prof_name("k_lin", "k_lin:%d>%d%s%s%s", v.KS * 16, nOT * 32, v.taps == 9 ? " 3x3" : "", R ? " +R" : "", M ? " *M" : ""));
     return 0;
 }
 // Linear / conv forward through view `view` (all of its output rows, or tiles [ot0, ot0 + nOT)): Y = act(X W^T) (+R)
@@ -258,6 +258,8 @@ int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, in
     const int nch = wg_chunks(N);
     long long len = (N + nch - 1) / nch;
     len = (len + 63) & ~63LL;
+    if (((len >> 2) + 2 * c.d.w + 48) * (long long)std::max(Co, Ci) * 4 >= (1LL << 32))     // k_wgrad addresses a wave's tokens with 32-bit byte offsets
+        return fail(LFT_ERR_SHAPE, "wgrad: %lld tokens per wave exceed the 32-bit offset range", len >> 2);
     const size_t poff = *c.part_used;
     *c.part_used += (size_t)nch * wsize;
     if (*c.part_used > c.T.part_floats) return fail(LFT_ERR_ARG, "internal: partial buffer overflow");
@@ -293,7 +295,7 @@ int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, in
         LFT_LAUNCH_WG(2, 1, g);
     }
 #undef LFT_LAUNCH_WG
-    LFT_LAUNCH_OK("k_wgrad");
+    LFT_LAUNCH_OK(prof_name("k_wgrad", "k_wgrad:%dx%d%s", Co, Ci, taps == 9 ? " 3x3" : ""));
     return red_push(c, poff, nch, (int)wsize, (int)wsize, dW, accumulate);
 }
 int red_push(const TrainCtx& c, size_t part_off, int nch, int n, int stride, float* dst, int chain) {

@@ -14,3 +14,5 @@ for math in ("bf16x3", "fp32"):
     r = t["roofline"]
     print(math, "step ms", round(t["ms_per_step"], 2), "patches/s", round(t["patches_per_s"], 1), r["families_ms"], "dominant", r["kernel"], r["bound"],
           "frac", round(r["frac"], 3))
+    for k, (ms, calls) in r["gemm_shapes_ms"].items():
+        print(f"    {k:28s} {ms:7.3f} ms  {calls:3d} calls  {ms / calls * 1e3:7.1f} us each")
