@@ -13,7 +13,20 @@ struct PackOp {
     const float* src;
     int kind, row0, nrows, ntiles, ld, kmul, kadd, k0, ksteps, kmap, frag0, s;
     float scale;
+    int order;     // 0: nt-major (frag = nt * ksteps + ks); 1: groups of 4 output tiles, inside a group ks-major (wfrag_index): the
+                   // fragments one workgroup of the training GEMM consumes are then ONE contiguous stream in consumption order
 };
+// Fragment (ot, ks) of a matrix of OT output tiles packed with order 1: groups of four tiles (the last one may hold fewer),
+// group g at 4 g KS, inside it k-step-major.
+__host__ __device__ __forceinline__ int wfrag_index(int OT, int KS, int ot, int ks) {
+    const int g = ot >> 2, G = OT - 4 * g < 4 ? OT - 4 * g : 4;
+    return 4 * g * KS + ks * G + (ot & 3);
+}
+__host__ __device__ __forceinline__ void wfrag_coords(int OT, int KS, int lf, int order, int& nt, int& ks) {
+    if (!order) { nt = lf / KS; ks = lf % KS; return; }
+    const int gl = (OT - 1) >> 2, g = lf / (4 * KS) < gl ? lf / (4 * KS) : gl, G = OT - 4 * g < 4 ? OT - 4 * g : 4, rem = lf - 4 * g * KS;
+    ks = rem / G; nt = 4 * g + rem % G;
+}
 constexpr int LFT_PACK_MAXOPS = 40;
 struct PackArgs {
     int nops;
@@ -38,7 +51,8 @@ __global__ __launch_bounds__(64) void k_pack(PackArgs args, T* __restrict__ dst)
     for (int i = 0; i < args.nops; ++i)
         if (f >= args.op[i].frag0) oi = i;
     const PackOp& op = args.op[oi];
-    const int lf = f - op.frag0, nt = lf / op.ksteps, ks = lf % op.ksteps;
+    int nt, ks;
+    wfrag_coords(op.ntiles, op.ksteps, f - op.frag0, op.order, nt, ks);
     const int n = 32 * nt + r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

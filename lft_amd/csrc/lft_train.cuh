@@ -12,6 +12,7 @@
 // All tensors are fp32 channels-last [token][channel]; token = ((b*V + v)*h + y)*w + x.
 #pragma once
 #include "lft_common.cuh"
+#include "lft_kernels_b.cuh"   // asm-issued loads with counted waits (ld16_async_ofs, wait_vm_q)
 
 // ------------------------------------------------------------------------------------------
 // Split-bf16 products ("bf16x3").  The fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) is 16x slower than the
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(64) void k_pack_split(PackArgs args, float* __restr
     for (int i = 0; i < args.nops; ++i)
         if (f >= args.op[i].frag0) oi = i;
     const PackOp& op = args.op[oi];
-    const int lf = f - op.frag0, nt = lf / op.ksteps, ks = lf % op.ksteps;
+    int nt, ks;
+    wfrag_coords(op.ntiles, op.ksteps, f - op.frag0, op.order, nt, ks);
     const int n = 32 * nt + r;
     bf16_t* d = reinterpret_cast<bf16_t*>(dst) + (size_t)f * 1024;                 // 2 KiB = 1024 bf16 per fragment
 #pragma unroll
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(64) void k_pack_split(PackArgs args, float* __restr
 // ------------------------------------------------------------------------------------------
 struct LinP {
     const float* X; int ldx;
-    const float* Wp; int OT, KS;      // packed fragments (k_pack, natural k order): frag (tap, ot, ks) at ((tap*OT + ot)*KS + ks)
+    const float* Wp; int OT, KS, ot0; // packed fragments of the whole view (k_pack order 1, natural k order): frag (tap, ot, ks) at tap*OT*KS + wfrag_index(OT, KS, ot, ks); ot0 = first output tile of this call
     const float* R; int ldr;          // optional: accumulator initialised with R (residual, or Y itself to accumulate)
     float* Y; int ldy;
     const float* M; int ldm, mact;    // optional backward-of-activation epilogue: Y = acc * act'(M), M = the saved activation OUTPUT (mact 1 relu, 2 lrelu)
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256, 3) void k_lin(const LinP p) {
     const long long t0 = ((long long)blockIdx.x * 4 + wave) * 32;
     if (t0 >= p.N) return;
     const int nvalid = (int)min((long long)32, p.N - t0);
-    const int ot0 = blockIdx.y * NT, o0 = ot0 * 32;
+    const int otl = blockIdx.y * NT, o0 = otl * 32, ot0 = p.ot0 + otl;     // otl: tile inside this call's output block (Y / R / M columns), ot0: tile of the view
     const long long t = min(t0 + r, p.N - 1);
     const int hw = p.h * p.w;
     const int pix = (int)(t % hw), y = pix / p.w, x = pix - y * p.w;
@@ -109,7 +111,6 @@ __global__ __launch_bounds__(256, 3) void k_lin(const LinP p) {
     else zero_acc<NT>(acc);
     if constexpr (TILED) {
         // plain Linear: the wave's 32 input rows are consecutive in memory -> coalesced 64-channel chunks through the scratch
-        const int fbase = ot0 * p.KS;
         for (int k0 = 0; k0 < p.KS; k0 += 4) {
             Frag<float> b[4];
             load_tile_frags_s<4, float>(p.X + t0 * p.ldx + 16 * k0, (size_t)p.ldx * 4, nvalid, lane, b, scr);
@@ -118,10 +119,10 @@ __global__ __launch_bounds__(256, 3) void k_lin(const LinP p) {
                 if constexpr (M3) {
                     const Frag2 b2 = split_frag(b[ks]);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) mma3(load_wfrag2(p.Wp, fbase + nt * p.KS + k0 + ks, lane), b2, acc[nt]);
+                    for (int nt = 0; nt < NT; ++nt) mma3(load_wfrag2(p.Wp, wfrag_index(p.OT, p.KS, ot0 + nt, k0 + ks), lane), b2, acc[nt]);
                 } else {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) mma(load_wfrag(p.Wp, fbase + nt * p.KS + k0 + ks, lane), b[ks], acc[nt]);
+                    for (int nt = 0; nt < NT; ++nt) mma(load_wfrag(p.Wp, wfrag_index(p.OT, p.KS, ot0 + nt, k0 + ks), lane), b[ks], acc[nt]);
                 }
             }
         }
@@ -131,16 +132,16 @@ __global__ __launch_bounds__(256, 3) void k_lin(const LinP p) {
         if (p.taps == 9) { dy = tap / 3 - 1; dx = tap % 3 - 1; if (p.flip) { dy = -dy; dx = -dx; } }
         const bool ok = (t0 + r < p.N) && (y + dy >= 0) && (y + dy < p.h) && (x + dx >= 0) && (x + dx < p.w);
         const float* row = p.X + (ok ? (t + dy * p.w + dx) : t) * p.ldx + 8 * kh;
-        const int fbase = (tap * p.OT + ot0) * p.KS;
+        const int fbase = tap * p.OT * p.KS;
         for (int ks = 0; ks < p.KS; ++ks) {
             const Frag<float> b = load_row8(row + 16 * ks, ok, 0.0f);
             if constexpr (M3) {
                 const Frag2 b2 = split_frag(b);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) mma3(load_wfrag2(p.Wp, fbase + nt * p.KS + ks, lane), b2, acc[nt]);
+                for (int nt = 0; nt < NT; ++nt) mma3(load_wfrag2(p.Wp, fbase + wfrag_index(p.OT, p.KS, ot0 + nt, ks), lane), b2, acc[nt]);
             } else {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) mma(load_wfrag(p.Wp, fbase + nt * p.KS + ks, lane), b, acc[nt]);
+                for (int nt = 0; nt < NT; ++nt) mma(load_wfrag(p.Wp, fbase + wfrag_index(p.OT, p.KS, ot0 + nt, ks), lane), b, acc[nt]);
             }
         }
     }
@@ -156,6 +157,124 @@ __global__ __launch_bounds__(256, 3) void k_lin(const LinP p) {
     if (p.M) {                                                           // dZ = dY * act'(Z), sign(Z) read off the saved act(Z)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {                                // one 32-channel tile at a time: 16 live registers, not 16 NT
+            f32x16 mk[1];
+            load_tile<1, float>(p.M + t0 * p.ldm + o0 + 32 * nt, nvalid, lane, mk, scr, (size_t)p.ldm * 4);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = mk[0][i] > 0.0f ? acc[nt][i] : (p.mact == 1 ? 0.0f : 0.2f * acc[nt][i]);
+        }
+    }
+    store_tile<NT, float>(p.Y + t0 * p.ldy + o0, nvalid, lane, acc, scr, (size_t)p.ldy * 4);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_lin with the weights through LDS.  The four waves of a workgroup (32 tokens each) multiply by the SAME NT x KS (x taps)
+// fragments; read per wave from L2 they are 4 KB per token against 1 KB of activations in and 1 KB out (a knock-out build
+// without the weight reads ran the family 20 % faster, one without the MFMAs not at all).  Here the group's fragments -- one
+// contiguous stream in consumption order (k_pack order 1) -- pass once per workgroup through the 3-slot LDS ring of the inference
+// kernels (as WRing: one chunk = one k-step's NT fragments, LDS-DMA two k-steps ahead, one barrier per k-step), and the activation
+// rows of the NEXT k-step are in flight while this one is multiplied.
+// Ordering (vmcnt retires in issue order).  The rows are ordinary loads: hipcc waits for them itself, so whatever it does with
+// the registers is safe (rows loaded from inline asm were COPIED in front of the asm wait that was to guard them).  Rows of
+// k-step s are issued in iteration s - 1, i.e. after the DMA of chunk s (behind barrier s - 2) and before that of chunk s + 1:
+// the compiler's wait for them -- pinned in front of barrier s -- therefore also covers this wave's pieces of chunk s, and
+// the ring needs no wait of its own.
+// LDS: ring slots 0, 1 | slot 2 overlaid by the waves' tile scratch -- the scratch is used before barrier 0 (residual tile)
+// and after the last k-step (activation-derivative tile, output tile); slot 2 is first written by the DMA behind barrier 0.
+// Requires: the call's output block is one packed group (NT == its tile count, first tile a multiple of 4); taps == 9: OT == NT.
+// ------------------------------------------------------------------------------------------
+template <int NT, bool M3>
+__global__ __launch_bounds__(256, 3) void k_linr(const LinP p) {
+    constexpr int CHUNK = NT * 2048, PPW = NT / 2;                        // bytes of weights per k-step; 1 KiB pieces per wave and chunk
+    constexpr int SCR = TileIO<NT, float>::BYTES;
+    static_assert(NT == 2 || NT == 4, "two or four output tiles");
+    __shared__ __attribute__((aligned(16))) char lds[2 * CHUNK + (4 * SCR > CHUNK ? 4 * SCR : CHUNK)];
+    const int lane = threadIdx.x & 63, r = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* scr = lds + 2 * CHUNK + wave * SCR;
+    const long long t0w = ((long long)blockIdx.x * 4 + wave) * 32;
+    const bool active = t0w < p.N;                                       // a wave past the end still runs the ring protocol (barriers, DMA share)
+    const long long t0 = active ? t0w : 0;
+    const int nvalid = active ? (int)min((long long)32, p.N - t0) : 0;
+    const int otl = blockIdx.y * NT, o0 = otl * 32, ot0 = p.ot0 + otl;
+    const long long t = min(t0 + r, p.N - 1);
+    const int hw = p.h * p.w;
+    const int pix = (int)(t % hw), y = pix / p.w, x = pix - y * p.w;
+    const int S = p.taps * p.KS;                                         // k-steps = ring chunks
+    // the ring: chunk c (the NT fragments of k-step c) in slot c % 3; every wave moves PPW pieces of it.  The DMA is issued from
+    // inline asm: hipcc does not know it, so its waits for the row loads are computed without it (stricter, never unsafe) and
+    // it does not guard the ring's LDS reads with a vmcnt(0) of its own (it did, with the builtin form)
+    const char* wsrc = reinterpret_cast<const char*>(p.Wp) + (size_t)wfrag_index(p.OT, p.KS, ot0, 0) * 2048 + (wave * PPW) * 1024 + lane * 16;
+    auto issue_w = [&](int c, int slot) {
+        if (c >= S) return;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) glds16_asm(wsrc + (size_t)c * CHUNK + i * 1024, lds + slot * CHUNK + (wave * PPW + i) * 1024);
+    };
+    issue_w(0, 0);
+    issue_w(1, 1);
+    f32x16 acc[NT];
+    if (p.R) load_tile<NT, float>(p.R + t0 * p.ldr + o0, nvalid, lane, acc, scr, (size_t)p.ldr * 4);
+    else zero_acc<NT>(acc);
+    // cursor of the next row load: (tap, k-step); past the last k-step it stays there (one redundant, cached reload)
+    int ctap = 0, cks = 0;
+    auto load_x = [&](bool& ok) -> Frag<float> {                         // raw rows; zeroed by `ok` where they are consumed (a select here would pull the wait up to here)
+        int dy = 0, dx = 0;
+        if (p.taps == 9) { dy = ctap / 3 - 1; dx = ctap % 3 - 1; if (p.flip) { dy = -dy; dx = -dx; } }
+        ok = (t0w + r < p.N) && (y + dy >= 0) && (y + dy < p.h) && (x + dx >= 0) && (x + dx < p.w);
+        const float* row = p.X + (ok ? (t + dy * p.w + dx) : t) * p.ldx + 8 * kh + 16 * cks;
+        if (cks + 1 < p.KS) ++cks; else if (ctap + 1 < p.taps) { cks = 0; ++ctap; }
+        return load_row8(row, true, 0.0f);
+    };
+    int cs = 0, slot = 0;                                                // current k-step and its ring slot
+    auto step = [&](const Frag<float>& xraw, bool ok) {
+        const Frag<float> xs = ok ? xraw : frag_zero(0.0f);
+        Frag2 b2;
+        if constexpr (M3) {
+            b2 = split_frag(xs);                                         // (the compiler's wait for the rows sits here, in front of the barrier)
+            asm volatile("" :: "v"(b2.hi.v), "v"(b2.lo.v));
+        } else {
+            asm volatile("" :: "v"(xs.lo), "v"(xs.hi));
+        }
+        wg_barrier_keep_vm();                                            // chunk cs published by every wave, chunk cs - 1 retired
+        issue_w(cs + 2, slot == 0 ? 2 : slot - 1);                       // into the slot chunk cs - 1 vacated
+        const char* base = lds + slot * CHUNK + lane * 16;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (M3) {
+                Frag2 w2;
+                w2.hi.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * 2048));
+                w2.lo.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * 2048 + 1024));
+                mma3(w2, b2, acc[nt]);
+            } else {
+                Frag<float> wf;
+                wf.lo = __builtin_bit_cast(f32x4, load_raw16(base + nt * 2048));
+                wf.hi = __builtin_bit_cast(f32x4, load_raw16(base + nt * 2048 + 1024));
+                mma(wf, xs, acc[nt]);
+            }
+        }
+        ++cs;
+        slot = slot == 2 ? 0 : slot + 1;
+    };
+    bool oka, okb;
+    Frag<float> xa = load_x(oka), xb;
+    for (int s = 0; s < S; s += 2) {                                    // S is even (KS is); two register sets, no copy between them
+        xb = load_x(okb);                                                // rows of k-step s + 1: in flight under this step's MFMAs
+        step(xa, oka);
+        xa = load_x(oka);
+        step(xb, okb);
+    }
+    wg_barrier_keep_vm();                                                // every wave is done with the ring: slot 2 is scratch again
+    if (p.act) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = acc[nt][i];
+                acc[nt][i] = v > 0.0f ? v : (p.act == 1 ? 0.0f : 0.2f * v);
+            }
+    }
+    if (p.M) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
             f32x16 mk[1];
             load_tile<1, float>(p.M + t0 * p.ldm + o0 + 32 * nt, nvalid, lane, mk, scr, (size_t)p.ldm * 4);
 #pragma unroll

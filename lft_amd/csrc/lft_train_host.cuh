@@ -49,7 +49,10 @@ WViews build_views(const float* const* P, int s, std::vector<PackOp>* ops) {
         v.frag0 = W.nfrags; v.OT = O / 32; v.KS = I / 16; v.taps = taps;
         W.nfrags += (size_t)taps * v.OT * v.KS;
         if (ops)
-            for (int t = 0; t < taps; ++t) ops->push_back(lin_op(src, 0, O, ld, 0, I / 16, 0, 1.0f, kmul, kadd + t * st));
+            for (int t = 0; t < taps; ++t) {
+                ops->push_back(lin_op(src, 0, O, ld, 0, I / 16, 0, 1.0f, kmul, kadd + t * st));
+                ops->back().order = 1;
+            }
     };
     auto fwd = [&](int id, const float* src, int O, int I, int row0 = 0) { add(id, src, O, I, 1, I, 1, row0 * I, 0); };
     auto bwd = [&](int id, const float* src, int O, int I, int row0 = 0) { add(id, src, I, O, 1, 1, I, row0 * I, 0); };   // W^T of rows row0..row0+O
@@ -81,7 +84,7 @@ WViews build_views(const float* const* P, int s, std::vector<PackOp>* ops) {
         W.nfrags += (size_t)gt * v.KS;
         if (ops) {
             PackOp m = lin_op(src(P_UP3), 0, gp, 0, 0, v.KS, 0, 1.0f);
-            m.kind = 1; m.s = s; m.ntiles = gt;
+            m.kind = 1; m.s = s; m.ntiles = gt; m.order = 1;
             ops->push_back(m);
         }
         WView& vb = W.v[VW_UPM_B];                    // its transpose: 64 s^2 rows, 32 gt columns (the padding columns are zero)
@@ -89,7 +92,7 @@ WViews build_views(const float* const* P, int s, std::vector<PackOp>* ops) {
         W.nfrags += (size_t)vb.OT * vb.KS;
         if (ops) {
             PackOp m = lin_op(src(P_UP3), 0, 64 * s * s, 0, 0, vb.KS, 0, 1.0f);
-            m.kind = 2; m.s = s;
+            m.kind = 2; m.s = s; m.order = 1;
             ops->push_back(m);
         }
     }
@@ -200,7 +203,7 @@ int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int l
     const WView& v = c.W.v[view];
     if (nOT <= 0) nOT = v.OT;
     if ((v.taps != 1 && (ot0 || nOT != v.OT))) return fail(LFT_ERR_ARG, "run_lin: bad tile block (view %d)", view);
-    LinP p{X, ldx, c.F(c.T.wp) + (v.frag0 + (size_t)ot0 * v.KS) * 512, v.OT, v.KS, R, ldr, Y, ldy, M, ldy, mact, v.taps, flip, act, c.d.h, c.d.w, N};
+    LinP p{X, ldx, c.F(c.T.wp) + v.frag0 * 512, v.OT, v.KS, ot0, R, ldr, Y, ldy, M, ldy, mact, v.taps, flip, act, c.d.h, c.d.w, N};
     const unsigned gx = (unsigned)((N + 127) / 128);
     // output tiles per wave: 4 when that still gives the chip >= 2 waves per SIMD, fewer (more, thinner waves) for small N
     const long long tiles = (N + 31) / 32;
@@ -208,13 +211,21 @@ int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int l
     while (nt > 1 && (nOT % nt || tiles * (nOT / nt) < 2048)) nt >>= 1;
     const dim3 g(gx, (unsigned)(nOT / nt));
     const bool m3 = c.math == LFT_MATH_BF16X3;
+    // weights through the LDS ring (k_linr) when every workgroup's output block is one packed group of the view: full groups of
+    // four tiles, or the view's last group of two; large N only (below, the coalesced-input form of k_lin is the faster one)
+    const bool full4 = nt == 4 && ot0 % 4 == 0 && ot0 + nOT <= (v.OT / 4) * 4;
+    const bool last2 = nt == 2 && nOT == 2 && v.OT % 4 == 2 && ot0 == (v.OT / 4) * 4;
+    const bool ring = N > 65536 && (full4 || last2) && (v.taps == 1 || nOT == v.OT);
     const bool tiled = v.taps == 1 && v.KS % 4 == 0 && N <= 65536;       // measured: +7 % at 25.6 k tokens, -4 % at 205 k
 #define LFT_LAUNCH_LIN(NTV)                                                                                          \
     do {                                                                                                             \
         if (m3) { if (tiled) k_lin<NTV, true, true><<<g, 256, 0, c.st>>>(p); else k_lin<NTV, true, false><<<g, 256, 0, c.st>>>(p); }      \
         else { if (tiled) k_lin<NTV, false, true><<<g, 256, 0, c.st>>>(p); else k_lin<NTV, false, false><<<g, 256, 0, c.st>>>(p); }     \
     } while (0)
-    if (nt == 4) LFT_LAUNCH_LIN(4); else if (nt == 2) LFT_LAUNCH_LIN(2); else LFT_LAUNCH_LIN(1);
+    if (ring) {
+        if (nt == 4) { if (m3) k_linr<4, true><<<g, 256, 0, c.st>>>(p); else k_linr<4, false><<<g, 256, 0, c.st>>>(p); }
+        else { if (m3) k_linr<2, true><<<g, 256, 0, c.st>>>(p); else k_linr<2, false><<<g, 256, 0, c.st>>>(p); }
+    } else if (nt == 4) LFT_LAUNCH_LIN(4); else if (nt == 2) LFT_LAUNCH_LIN(2); else LFT_LAUNCH_LIN(1);
 #undef LFT_LAUNCH_LIN
     LFT_LAUNCH_OK(prof_name("k_lin", "k_lin:%d>%d%s%s%s", v.KS * 16, nOT * 32, v.taps == 9 ? " 3x3" : "", R ? " +R" : "", M ? " *M" : ""));
     return 0;

@@ -399,12 +399,16 @@ def test_fit_trains_and_writes_reference_format_checkpoints(tmp_path):
         assert torch.equal(fresh(lr), net.eval()(lr))
 
 
-def test_full_size_backward_properties_cfg3():
+@pytest.mark.parametrize("math", MATHS)
+def test_full_size_backward_properties_cfg3(math):
     """BASELINE configs[2] shape (A5, 2x, 32x32 LR views), where autograd over the CPU oracle takes minutes: properties
     that hold at any size instead.  For a fixed forward the backward pass is linear in d loss / d out, and patches never
-    interact, so (i) grads(a*g1 + g2) = a*grads(g1) + grads(g2), (ii) the gradient of a 2-patch batch is the sum of the
-    per-patch gradients; and the forward-with-tape must agree with the fused inference kernels."""
-    A, s, B, h, w = 5, 2, 2, 32, 32
+    interact, so (i) grads(a*g1 + g2) = a*grads(g1) + grads(g2), (ii) the gradient of a 3-patch batch is the sum of the
+    per-patch gradients; and the forward-with-tape must agree with the fused inference kernels.  Three patches are 76 800 tokens:
+    the batch runs the ring-fed GEMM kernel (k_linr, above 65 536 tokens), the single patches the direct one (k_lin) -- (ii) and
+    the forward comparison hold the two against each other and against the inference path."""
+    A, s, B, h, w = 5, 2, 3, 32, 32
+    tol = {"fp32": 2e-5, "bf16x3": 1e-4}[math]
     sd_np = deterministic_state(64, s, seed=1, flavor="stress")
     names = [n for n, _, _ in param_table(64, s)]
     ps = [torch.from_numpy(sd_np[n]).to(G.DEV).contiguous() for n in names]
@@ -412,24 +416,26 @@ def test_full_size_backward_properties_cfg3():
     g = torch.Generator(device="cpu").manual_seed(5)
     g1 = torch.randn(B, 1, A * h * s, A * w * s, generator=g).to(G.DEV) * 1e-3
     g2 = torch.randn(B, 1, A * h * s, A * w * s, generator=g).to(G.DEV) * 1e-3
-    out, tape = T.train_forward(ps, lr, A, s)
-    ga = T.train_backward(ps, lr, tape, g1, A, s).clone()
-    gb = T.train_backward(ps, lr, tape, g2, A, s).clone()
-    gc = T.train_backward(ps, lr, tape, 0.5 * g1 + g2, A, s).clone()
+    out, tape = T.train_forward(ps, lr, A, s, math=math)
+    ga = T.train_backward(ps, lr, tape, g1, A, s, math=math).clone()
+    gb = T.train_backward(ps, lr, tape, g2, A, s, math=math).clone()
+    gc = T.train_backward(ps, lr, tape, 0.5 * g1 + g2, A, s, math=math).clone()
     scale = float(gc.abs().max())
-    assert float((gc - (0.5 * ga + gb)).abs().max()) <= 2e-5 * scale
-    per = []
+    assert float((gc - (0.5 * ga + gb)).abs().max()) <= tol * scale
+    per, outs = [], []
     for i in range(B):
-        _, tp = T.train_forward(ps, lr[i:i + 1], A, s)
-        per.append(T.train_backward(ps, lr[i:i + 1], tp, g1[i:i + 1].contiguous(), A, s).clone())
-    assert float((ga - (per[0] + per[1])).abs().max()) <= 2e-5 * float(ga.abs().max())
+        o1, tp = T.train_forward(ps, lr[i:i + 1], A, s, math=math)
+        outs.append(o1.clone())
+        per.append(T.train_backward(ps, lr[i:i + 1], tp, g1[i:i + 1].contiguous(), A, s, math=math).clone())
+    assert float((ga - sum(per)).abs().max()) <= tol * float(ga.abs().max())
+    assert float((out - torch.cat(outs)).abs().max()) <= tol * float(out.abs().max())
     # forward-with-tape (unfused fp32 kernels) vs the fused fp32 inference kernels
     from model import LFT
     net = LFT.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=s), precision="fp32")
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
     with torch.no_grad():
         y = net.to(G.DEV).eval()(lr)
-    assert float((y - out).abs().max() / y.abs().max()) <= 1e-5
+    assert float((y - out).abs().max() / y.abs().max()) <= (1e-5 if math == "fp32" else 1e-4)
 
 
 def test_training_is_bitwise_reproducible():
