@@ -112,12 +112,14 @@ struct TrainLayout {
     size_t bwd, bwd_floats, gu, stats, part, pgb;       // bwd: arena of the backward pass's gradient tensors (re-used as they die)
     size_t part_floats, total;                   // total in floats
 };
+constexpr int kWgChunksMax = 512;                // ... raised up to this for small matrices (wgrad)
 constexpr int kWgChunks = 128;                   // token chunks (= workgroups of 4 waves) of a weight-gradient launch
 constexpr int kLnBlocks = 512;                   // workgroups (= partial rows) of a LayerNorm backward
 constexpr int kTailWaves = 2048;                 // waves of the up-sampler / conv0 weight-gradient kernels
 inline int wg_chunks(long long N) { return (int)std::min<long long>(kWgChunks, std::max<long long>(4, N / 512)); }   // workgroups of 4 waves, >= 128 tokens per wave
 
-size_t bwd_arena_peak(const Dims& d);
+struct BwdSizes { size_t arena, part; };           // floats: peak live set of the gradient arena, high-water mark of the partial sums
+BwdSizes bwd_sizes(const Dims& d);
 TrainLayout train_layout(const Dims& d) {
     TrainLayout T;
     size_t o = 0;
@@ -141,17 +143,17 @@ TrainLayout train_layout(const Dims& d) {
     // The gradient tensors of the backward pass live in an arena and are released at their last use (train_backward: every
     // kernel of a pass runs on ONE stream, so a buffer may be handed out again as soon as its last reader is enqueued); the
     // arena is as large as the pass's peak live set, found by running the pass's own allocation sequence without launching
-    // anything (bwd_arena_peak).  Round 2 gave every tensor a buffer of its own (40 KB per token) so that the weight-gradient
+    // anything (bwd_sizes).  Round 2 gave every tensor a buffer of its own (40 KB per token) so that the weight-gradient
     // kernels could run on a second stream: that overlap bought 3 % and cost half of the tape.
-    T.bwd_floats = bwd_arena_peak(d);
+    const BwdSizes bsz = bwd_sizes(d);
+    T.bwd_floats = bsz.arena;
     T.bwd = take(T.bwd_floats);
     T.gu = take(n * 64 * ss);
     T.stats = take(n * 8 * 3);
     // Partial sums (weight gradients per token chunk, LayerNorm rows, tails) are reduced at the end of every LAYER of the
-    // backward pass (k_reduce_all) and the region is re-used by the next one: sized for the largest -- one layer plus the
-    // up-sampler -- not for all parameters at once (round 2: 0.6 GB at B = 8).
-    T.part_floats = (size_t)wg_chunks(d.ntok) * ((size_t)param_info(d.s).total / 4 + (size_t)2 * 64 * 64 * ss + 8192) + (size_t)wg_chunks(d.hw) * 128 * 576
-                    + (size_t)4 * kLnBlocks * 256 + (size_t)2 * kTailWaves * 576;
+    // backward pass (k_reduce_all) and the region is re-used by the next one: as large as the largest layer's, from the same dry
+    // run (round 2 kept all parameters' partials at once: 0.6 GB at B = 8).
+    T.part_floats = bsz.part;
     T.part = take(T.part_floats);
     T.pgb = 0;
     T.total = o;
@@ -190,12 +192,21 @@ struct TrainCtx {
     int math;                  // LFT_MATH_F32 or LFT_MATH_BF16X3
     RedTab* red = nullptr;     // backward only: pending reductions (k_reduce_all) ...
     size_t* part_used = nullptr;   // ... and the next free float of the partial buffer
+    size_t* part_peak = nullptr;   // its high-water mark (the dry run sizes the buffer with it)
     const float* gbase = nullptr;  // flat gradient buffer (segment destinations are offsets into it)
     hipStream_t side = nullptr;    // (unused since the arena: every kernel of a pass runs on `st`)
     bool dry = false;              // sizing pass: allocation sequence only, nothing is launched
     float* F(size_t off) const { return tp + off; }
 };
 
+// n floats of the partial-sum buffer (released as a whole by the next k_reduce_all)
+int part_take(const TrainCtx& c, size_t n, size_t* off) {
+    *off = *c.part_used;
+    *c.part_used += n;
+    if (c.part_peak && *c.part_used > *c.part_peak) *c.part_peak = *c.part_used;
+    if (!c.dry && *c.part_used > c.T.part_floats) return fail(LFT_ERR_ARG, "internal: partial buffer overflow");
+    return 0;
+}
 // Y[N][ldy cols o0..] = act(X W(view)^T) (+R).  ot0 / nOT select a block of the view's output tiles (taps == 1 only).
 int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int ldx, int flip, int act, const float* R, int ldr,
             float* Y, int ldy, long long N, const float* M = nullptr, int mact = 0) {
@@ -263,17 +274,29 @@ hipEvent_t next_event() {
 }
 // weight gradient of either: dW (+)= dY^T X  (taps = 1 or 9)
 int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, int taps, float* dW, int accumulate, long long N) {
-    if (c.dry) return 0;
     if (Co % 32 || Ci % 64) return fail(LFT_ERR_ARG, "wgrad: Co %d / Ci %d not supported", Co, Ci);
+    if (taps == 9 && Ci != 64) return fail(LFT_ERR_ARG, "wgrad: 3x3 with Ci %d not supported", Ci);   // all 3x3 convolutions of the network have Ci = 64
     const long long wsize = (long long)Co * Ci * taps;
-    const int nch = wg_chunks(N);
+    // Token chunks.  A chunk is gridy workgroups (one per output tile x input group x tap row); the launch should fill the chip in
+    // WHOLE rounds of resident workgroups (MI355X: 256 CUs x 2 / 3 / 4 workgroups by the variant's registers): at the fixed 128
+    // chunks a 64x64 weight put ONE wave on every SIMD, which alternated between waiting for its loads and multiplying (92 us
+    // exact, 11 us of matrix work), while 1 024 workgroups on 768 slots ran a second round a third full.
+    const int gridy = taps == 9 ? Co / 32 * 3 : Co / 32 * (Ci % 128 == 0 ? Ci / 128 : Ci / 64);
+    const int slots = 256 * (taps == 9 ? 2 : Ci % 128 == 0 ? 3 : 4);
+    const int base = wg_chunks(N), rounds = std::max(1, (base * gridy + slots - 1) / slots);
+    int nch = std::min<long long>(std::min(kWgChunksMax, rounds * slots / gridy), std::max<long long>(base, N / 256));
+    // split-bf16 products are 5x cheaper, the loop is bound by its loads and conversions and a workgroup's epilogue (LDS sum of
+    // the four waves, partial image) weighs more: measured, more chunks pay only where the launch filled under a quarter of the chip
+    if (c.math == LFT_MATH_BF16X3 && base * gridy * 4 > slots) nch = base;
+    nch = std::max(nch, 1);
     long long len = (N + nch - 1) / nch;
     len = (len + 63) & ~63LL;
     if (((len >> 2) + 2 * c.d.w + 48) * (long long)std::max(Co, Ci) * 4 >= (1LL << 32))     // k_wgrad addresses a wave's tokens with 32-bit byte offsets
         return fail(LFT_ERR_SHAPE, "wgrad: %lld tokens per wave exceed the 32-bit offset range", len >> 2);
-    const size_t poff = *c.part_used;
-    *c.part_used += (size_t)nch * wsize;
-    if (*c.part_used > c.T.part_floats) return fail(LFT_ERR_ARG, "internal: partial buffer overflow");
+    size_t poff;
+    int rc;
+    if ((rc = part_take(c, (size_t)nch * wsize, &poff))) return rc;
+    if (c.dry) return 0;
     hipStream_t ws = c.st;
     if (c.side) {                                      // dY was produced by the last kernel enqueued on the main stream
         hipEvent_t ev = next_event();
@@ -284,15 +307,13 @@ int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, in
     }
     WgP p{dY, Co, X, Ci, c.F(c.T.part) + poff, wsize, Ci * taps, taps, 1, Co, Ci, taps, c.d.h, c.d.w, N, len, 1};
     const bool m3 = c.math == LFT_MATH_BF16X3;
-    int rc;
 #define LFT_LAUNCH_WG(NIV, TXV, GRID)                                                                                  \
     do {                                                                                                               \
         const size_t lds = (size_t)3 * TXV * NIV * 16 * 64 * sizeof(float);                                            \
         if (m3) { if ((rc = allow_lds(k_wgrad<NIV, true, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, true, TXV><<<GRID, 256, lds, ws>>>(p); }   \
         else { if ((rc = allow_lds(k_wgrad<NIV, false, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, false, TXV><<<GRID, 256, lds, ws>>>(p); }    \
     } while (0)
-    if (taps == 9) {                                  // all 3x3 convolutions of the network have Ci = 64
-        if (Ci != 64) return fail(LFT_ERR_ARG, "wgrad: 3x3 with Ci %d not supported", Ci);
+    if (taps == 9) {
         p.igroups = 1;
         const dim3 g((unsigned)nch, (unsigned)(Co / 32), 3u);
         LFT_LAUNCH_WG(2, 3, g);
@@ -332,11 +353,11 @@ int ln_fwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, 
 // out = (add ? add : 0) + dLN/du ; dgamma, dbeta written
 int ln_bwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, const float* g, const float* dY, const float* add,
            float* out, float* dgamma, float* dbeta, long long N) {
-    if (c.dry) return 0;
     const int nb = (int)std::min<long long>(kLnBlocks, (N + 15) / 16);
-    const size_t poff = *c.part_used;
-    *c.part_used += (size_t)nb * 2 * C;
-    if (*c.part_used > c.T.part_floats) return fail(LFT_ERR_ARG, "internal: partial buffer overflow");
+    size_t poff;
+    int rc;
+    if ((rc = part_take(c, (size_t)nb * 2 * C, &poff))) return rc;
+    if (c.dry) return 0;
     float* pgb = c.F(c.T.part) + poff;
     if (C == 64) k_ln_bwd<64><<<nb, 256, 0, c.st>>>(X, pe, mode, g, dY, add, out, pgb, N, c.d.hw, c.d.V);
     else k_ln_bwd<128><<<nb, 256, 0, c.st>>>(X, pe, mode, g, dY, add, out, pgb, N, c.d.hw, c.d.V);
@@ -493,14 +514,14 @@ struct BwdArena {
 // dry: the allocation sequence only (P, lr, tape, dout, G may be null) -- returns the arena's peak through *peak_out.
 int train_backward(const float* const* P, const float* lr, float* tape, const float* dout, float* G, const Dims& d, int math,
                    hipStream_t st, hipStream_t /*side: unused, kept for the ABI*/, BucketFn on_bucket = nullptr, void* user = nullptr,
-                   bool dry = false, size_t* peak_out = nullptr) {
+                   bool dry = false, size_t* peak_out = nullptr, size_t* part_peak_out = nullptr) {
     TrainLayout Tdry{};
     const TrainLayout T = dry ? Tdry : train_layout(d);
     const WViews WV = build_views(nullptr, d.s, nullptr);            // packed by this step's lft_train_forward
     RedTab red{};                                                    // every partial-sum producer registers a segment here
-    size_t part_used = 0;
+    size_t part_used = 0, part_peak = 0;
     static float dummy_base[64];
-    TrainCtx c{d, dry ? dummy_base : tape, T, WV, st, math, &red, &part_used, G, nullptr};
+    TrainCtx c{d, dry ? dummy_base : tape, T, WV, st, math, &red, &part_used, &part_peak, G, nullptr};
     c.dry = dry;
     const ParamInfo pi = param_info(d.s);
     const long long N = d.ntok;
@@ -677,14 +698,15 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
     float* dx0 = nb(64);
     TRY(lin_bwd(c, VW_CONV_B + 0, dz1, dfeat, dx0, N));                                    // d x0 = d feat + conv path
     A.put(dz1); A.put(dfeat);
+    size_t poff0;
+    TRY(part_take(c, (size_t)kTailWaves * 576, &poff0));
     if (peak_out) *peak_out = A.peak;
+    if (part_peak_out) *part_peak_out = part_peak;
     if (dry) return 0;
     if (A.peak > T.bwd_floats) return fail(LFT_ERR_ARG, "internal: backward arena overflow (%zu > %zu)", A.peak, T.bwd_floats);
     {
         const long long per = (N + kTailWaves - 1) / kTailWaves;
-        const size_t poff = part_used;
-        part_used += (size_t)kTailWaves * 576;
-        if (part_used > T.part_floats) return fail(LFT_ERR_ARG, "internal: partial buffer overflow");
+        const size_t poff = poff0;
         k_conv0_wgrad<<<kTailWaves / 4, 256, 0, st>>>(dx0, lr, c.F(T.part) + poff, d.B, d.A, d.h, d.w, per);
         LFT_LAUNCH_OK("k_conv0_wgrad");
         TRY(red_push(c, poff, kTailWaves, 576, 576, g(P_CONV0), 0));
@@ -693,13 +715,13 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
 #undef TRY
     return 0;
 }
-size_t bwd_arena_peak(const Dims& d) {
+BwdSizes bwd_sizes(const Dims& d) {
     // the pass's own allocation sequence, nothing launched; cached for the last shape (every entry point computes the layout)
     static thread_local Dims last{};
-    static thread_local size_t last_peak = 0;
-    if (last_peak && last.B == d.B && last.A == d.A && last.h == d.h && last.w == d.w && last.s == d.s) return last_peak;
-    size_t peak = 0;
-    (void)train_backward(nullptr, nullptr, nullptr, nullptr, nullptr, d, LFT_MATH_F32, nullptr, nullptr, nullptr, nullptr, true, &peak);
-    last = d; last_peak = peak;
-    return peak;
+    static thread_local BwdSizes last_sz{};
+    if (last_sz.arena && last.B == d.B && last.A == d.A && last.h == d.h && last.w == d.w && last.s == d.s) return last_sz;
+    BwdSizes sz{};
+    (void)train_backward(nullptr, nullptr, nullptr, nullptr, nullptr, d, LFT_MATH_F32, nullptr, nullptr, nullptr, nullptr, true, &sz.arena, &sz.part);
+    last = d; last_sz = sz;
+    return sz;
 }
