@@ -739,13 +739,32 @@ constexpr int kWaTY = 8, kWaTX = 16, kWaHR = kWaTY + 4, kWaHC = kWaTX + 4, kWaSl
 constexpr int kWaTile = kWaSlots * kWaRow;                     // floats per staged tensor
 constexpr size_t kWaLds = (size_t)(2 * kWaTile + kWaSlots * 6) * sizeof(float);
 
-LFT_DEV void wa_stage(const float* __restrict__ src, int ld, float* lds, long long img0, int y0, int x0, int hp, int h, int w) {
-    for (int idx = threadIdx.x; idx < kWaSlots * 8; idx += 256) {
+// Both halo tiles of a pass: ALL of a thread's 16-byte pieces (8 per tensor) are requested before the first one is written to
+// LDS -- as a load / wait / write loop the staging was 16 serialised memory round trips per workgroup, most of the kernel's time.
+LFT_DEV void wa_stage2(const float* __restrict__ srcA, int ldA, float* ldsA, const float* __restrict__ srcB, int ldB, float* ldsB,
+                       long long img0, int y0, int x0, int hp, int h, int w) {
+    constexpr int NIT = (kWaSlots * 8 + 255) / 256;
+    f32x4 va[NIT], vb[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = min((int)threadIdx.x + 256 * i, kWaSlots * 8 - 1);
         const int slot = idx >> 3, piece = idx & 7;
         const int gy = y0 - 2 + slot / kWaHC, gx = x0 - 2 + slot % kWaHC;
         const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
-        const f32x4 v = load4(src + (size_t)(in ? img0 + gy * w + gx : img0) * ld + hp * 32 + piece * 4);
-        *reinterpret_cast<f32x4*>(lds + slot * kWaRow + piece * 4) = in ? v : f32x4{0, 0, 0, 0};
+        const size_t t = (size_t)(in ? img0 + gy * w + gx : img0);
+        va[i] = load4(srcA + t * ldA + hp * 32 + piece * 4);
+        vb[i] = load4(srcB + t * ldB + hp * 32 + piece * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = (int)threadIdx.x + 256 * i;
+        const int slot = idx >> 3, piece = idx & 7;
+        const int gy = y0 - 2 + slot / kWaHC, gx = x0 - 2 + slot % kWaHC;
+        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+        if (idx < kWaSlots * 8) {
+            *reinterpret_cast<f32x4*>(ldsA + slot * kWaRow + piece * 4) = in ? va[i] : f32x4{0, 0, 0, 0};
+            *reinterpret_cast<f32x4*>(ldsB + slot * kWaRow + piece * 4) = in ? vb[i] : f32x4{0, 0, 0, 0};
+        }
     }
 }
 LFT_DEV void lds16(const float* p, float (&o)[16]) {
@@ -778,24 +797,40 @@ __global__ __launch_bounds__(256, 2) void k_win_attn_lds(const float* __restrict
     const long long tok = img0 + min(y, h - 1) * w + min(x, w - 1);
     const size_t off = (size_t)tok * 128 + hp * 32 + hl * 16, offq = (size_t)tok * ldq + hp * 32 + hl * 16;
     const float scale = 0.25f, scale2 = PRESCALED ? 1.0f : 0.25f * LFT_LOG2E;
-    wa_stage(MODE == 2 ? Q : K, ldq, tA, img0, y0, x0, hp, h, w);
-    wa_stage(MODE == 2 ? dO : Vv, 128, tB, img0, y0, x0, hp, h, w);
+    // this thread's own rows: requested before the staging so that they arrive under it
+    float own_a[16], own_b[16];
+    if (MODE == 0 || MODE == 1) { ld16(Q + offq, own_a); if (MODE == 1) ld16(dO + off, own_b); }
     if (MODE == 2) {
-        for (int idx = threadIdx.x; idx < kWaSlots * 6; idx += 256) {
+        constexpr int NS = (kWaSlots * 6 + 255) / 256;
+        float sv[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int idx = min((int)threadIdx.x + 256 * i, kWaSlots * 6 - 1);
             const int slot = idx / 6, e = idx % 6;
             const int gy = y0 - 2 + slot / kWaHC, gx = x0 - 2 + slot % kWaHC;
             const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
-            tS[idx] = in ? stats[((size_t)(img0 + gy * w + gx) * 8 + hp * 2) * 3 + e] : 0.0f;
+            sv[i] = stats[((size_t)(in ? img0 + gy * w + gx : img0) * 8 + hp * 2) * 3 + e];
         }
+        wa_stage2(Q, ldq, tA, dO, 128, tB, img0, y0, x0, hp, h, w);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int idx = (int)threadIdx.x + 256 * i;
+            const int slot = idx / 6;
+            const int gy = y0 - 2 + slot / kWaHC, gx = x0 - 2 + slot % kWaHC;
+            const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+            if (idx < kWaSlots * 6) tS[idx] = in ? sv[i] : 0.0f;
+        }
+    } else {
+        wa_stage2(K, ldq, tA, Vv, 128, tB, img0, y0, x0, hp, h, w);
     }
     __syncthreads();
     const float* bA = tA + (qy * kWaHC + qx) * kWaRow + hl * 16;          // tap (ty, tx) adds (ty * kWaHC + tx) * kWaRow
     const float* bB = tB + (qy * kWaHC + qx) * kWaRow + hl * 16;
     if (MODE == 0 || MODE == 1) {
         const int wy0 = max(0, y - 2), wy1 = min(h, y + 3), wx0 = max(0, x - 2), wx1 = min(min(h, x + 3), w);   // LFT.py:150-160 (sic)
-        float q[16], kv[16], vv[16], dov[16], sc[25];
-        ld16(Q + offq, q);
-        if (MODE == 1) ld16(dO + off, dov);
+        float kv[16], vv[16], sc[25];
+        const float (&q)[16] = own_a;
+        const float (&dov)[16] = own_b;
         float m = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 25; ++t) {
@@ -841,20 +876,23 @@ __global__ __launch_bounds__(256, 2) void k_win_attn_lds(const float* __restrict
         }
     } else {
         float kj[16], vj[16], qv[16], dv16[16], dk[16], dv[16];
-        ld16(K + offq, kj);
+        ld16(K + offq, kj);                                              // (pass B: the staging's 16 pieces + stats leave no registers to request these earlier)
         ld16(Vv + off, vj);
 #pragma unroll
         for (int c = 0; c < 16; ++c) { dk[c] = 0.0f; dv[c] = 0.0f; }
         const float* bS = tS + (qy * kWaHC + qx) * 6 + hl * 3;
+#pragma unroll 1
+        for (int wy = 0; wy < 5; ++wy) {                                  // a rolled loop over the window's rows: fully unrolled, the scheduler hoists the LDS reads of all 25 taps and spills
 #pragma unroll
-        for (int t = 0; t < 25; ++t) {
-            const int so = (t / 5) * kWaHC + t % 5;
-            lds16(bA + so * kWaRow, qv);
-            lds16(bB + so * kWaRow, dv16);
-            const float pij = fast_exp2(scale2 * dot16(qv, kj) - bS[so * 6]) * bS[so * 6 + 1];     // 1/l = 0 outside the image
-            const float ds = pij * (dot16(dv16, vj) - bS[so * 6 + 2]);
+            for (int wx = 0; wx < 5; ++wx) {
+                const int so = wy * kWaHC + wx;
+                lds16(bA + so * kWaRow, qv);
+                lds16(bB + so * kWaRow, dv16);
+                const float pij = fast_exp2(scale2 * dot16(qv, kj) - bS[so * 6]) * bS[so * 6 + 1];     // 1/l = 0 outside the image
+                const float ds = pij * (dot16(dv16, vj) - bS[so * 6 + 2]);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) { dk[c] += ds * qv[c]; dv[c] += pij * dv16[c]; }
+                for (int c = 0; c < 16; ++c) { dk[c] += ds * qv[c]; dv[c] += pij * dv16[c]; }
+            }
         }
         if (!valid) return;
         const float seen = x < h ? 1.0f : 0.0f;                            // keys with x >= h are in nobody's window (the column bound uses h)
