@@ -144,3 +144,15 @@ def test_gradient_buckets_tile_the_flat_buffer():
         assert spans[1][0] == starts["altblock.0.spa_trans.MLP.weight"]
         assert spans[0][0] == starts["altblock.2.spa_trans.MLP.weight"]
     assert L.lft_train_grad_bucket(2, 3, ctypes.byref(first), ctypes.byref(count)) != 0
+
+
+def test_no_asm_loaded_register_is_read_before_its_wait():
+    """Both units assembled with the product flags (no GPU needed): a register filled by an inline-asm global load must not be
+    read -- hipcc copies such registers to set up tied asm operands -- before the counted s_waitcnt that guards it
+    (tools/asm_load_hazards.py; the first k_linr did exactly that and passed every test in fp32)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "asm_load_hazards.py"), "--build"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 suspicious read(s)" in r.stdout
