@@ -111,9 +111,15 @@ __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, con
     // bank conflicts).  9 taps padded to 12 floats per channel = three 16-byte reads; channel groups 100 floats apart put the
     // eight distinct addresses of a 16-lane group on disjoint banks.
     __shared__ __attribute__((aligned(16))) float wl[8 * 100];
-    for (int i = threadIdx.x; i < 576; i += 256) {
-        const int ch = i / 9, t = i - ch * 9;
-        wl[(ch >> 3) * 100 + (ch & 7) * 12 + t] = w0[i];
+    {   // all three loads of a thread in flight before the first LDS write (as a load / wait / write loop: three serialised round trips)
+        float wv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wv[k] = w0[min((int)threadIdx.x + 256 * k, 575)];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = (int)threadIdx.x + 256 * k, ch = i / 9, t = i - ch * 9;
+            if (i < 576) wl[(ch >> 3) * 100 + (ch & 7) * 12 + t] = wv[k];
+        }
     }
     __syncthreads();
     const int hw = h * w, im = blockIdx.y, V = A * A;

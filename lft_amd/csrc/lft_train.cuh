@@ -424,6 +424,13 @@ __global__ __launch_bounds__(256) void k_reduce_all(const RedTab tab, const floa
     if (i < sg.n) {
         const float* p1 = part + sg.part_off + i;
         int c = yl;
+        for (; c + 28 < sg.nch; c += 32) {                              // eight loads in flight; each accumulator sees its chunks in the same order as before
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p1[(long long)(c + 4 * k) * sg.stride];
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) { s0 += v[k]; s1 += v[k + 1]; }
+        }
         for (; c + 4 < sg.nch; c += 8) { s0 += p1[(long long)c * sg.stride]; s1 += p1[(long long)(c + 4) * sg.stride]; }
         if (c < sg.nch) s0 += p1[(long long)c * sg.stride];
         const float* p2 = part + sg.part2_off + i;
@@ -596,7 +603,15 @@ __global__ void k_sum_images(const float* __restrict__ src, int nimg, long long 
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.0f;
-    for (int im = 0; im < nimg; ++im) s += src[(long long)im * n + i];
+    int im = 0;
+    for (; im + 8 <= nimg; im += 8) {                                   // eight loads in flight, added in image order (the sum's order is unchanged)
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[(long long)(im + k) * n + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; im < nimg; ++im) s += src[(long long)im * n + i];
     out[i] = s;
 }
 
