@@ -355,7 +355,17 @@ def train_object(dev, math: str, with_roofline: bool = False):
             else:
                 roof.update(bound="hbm", achieved=gbyte / (t_ms * 1e-3), peak=HBM_PEAK_GBS, unit="GB/s", frac=gbyte / (t_ms * 1e-3) / HBM_PEAK_GBS)
             roof["algorithmic_per_step"] = {"gbyte": gbyte, "gflop": gflop, "calls": work["calls"]}
-            roof["traffic"] = None                       # PMC passes of the training step: profiles/r03_train_* (not read back here)
+            # HBM bytes per step of the family from the committed PMC passes of the training step (tools/collect_train_traffic.py),
+            # only for the sources and the math mode they were taken on
+            roof["traffic"] = None
+            tp = os.path.join(ROOT, "profiles", f"r03_train_hbm_traffic_{math}.json")
+            if os.path.exists(tp):
+                prof = json.load(open(tp))
+                if prof.get("source_hash") == source_hash() and dom in prof["kernels"]:
+                    roof["traffic"] = prof["kernels"][dom]["total"]
+                    roof["traffic_source"] = os.path.relpath(tp, ROOT)
+                else:
+                    roof["traffic_note"] = "%s was taken on other sources (hash %s)" % (os.path.relpath(tp, ROOT), prof.get("source_hash"))
         out["roofline"] = roof
         del tape, o, g
     del ts, net
