@@ -194,7 +194,6 @@ struct TrainCtx {
     size_t* part_used = nullptr;   // ... and the next free float of the partial buffer
     size_t* part_peak = nullptr;   // its high-water mark (the dry run sizes the buffer with it)
     const float* gbase = nullptr;  // flat gradient buffer (segment destinations are offsets into it)
-    hipStream_t side = nullptr;    // (unused since the arena: every kernel of a pass runs on `st`)
     bool dry = false;              // sizing pass: allocation sequence only, nothing is launched
     float* F(size_t off) const { return tp + off; }
 };
@@ -253,25 +252,6 @@ int lin_bwd(const TrainCtx& c, int view, const float* dY, const float* R, float*
     const WView& v = c.W.v[view];
     return run_lin(c, view, 0, 0, dY, v.KS * 16, 1, 0, R, v.OT * 32, dX, v.OT * 32, N, M, mact);
 }
-// Events ordering the side stream after the producers on the main stream (host objects, created once per thread and reused;
-// a re-record only affects waits enqueued after it).
-hipEvent_t next_event() {
-    // one pool per (thread, device): an event belongs to the device that was current when it was created
-    struct Pool { std::vector<hipEvent_t> ev; size_t cursor = 0; };
-    static thread_local std::vector<Pool> pools;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
-    if ((size_t)dev >= pools.size()) pools.resize((size_t)dev + 1);
-    Pool& p = pools[(size_t)dev];
-    if (p.cursor >= p.ev.size()) {
-        hipEvent_t e = nullptr;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        p.ev.push_back(e);
-    }
-    hipEvent_t e = p.ev[p.cursor];
-    p.cursor = (p.cursor + 1) % 256;                   // far more than one backward pass records
-    return e;
-}
 // weight gradient of either: dW (+)= dY^T X  (taps = 1 or 9)
 int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, int taps, float* dW, int accumulate, long long N) {
     if (Co % 32 || Ci % 64) return fail(LFT_ERR_ARG, "wgrad: Co %d / Ci %d not supported", Co, Ci);
@@ -298,13 +278,6 @@ int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, in
     if ((rc = part_take(c, (size_t)nch * wsize, &poff))) return rc;
     if (c.dry) return 0;
     hipStream_t ws = c.st;
-    if (c.side) {                                      // dY was produced by the last kernel enqueued on the main stream
-        hipEvent_t ev = next_event();
-        if (!ev) return fail(LFT_ERR_ARG, "hipEventCreate failed");
-        LFT_HIP_OK(hipEventRecord(ev, c.st));
-        LFT_HIP_OK(hipStreamWaitEvent(c.side, ev, 0));
-        ws = c.side;
-    }
     WgP p{dY, Co, X, Ci, c.F(c.T.part) + poff, wsize, Ci * taps, taps, 1, Co, Ci, taps, c.d.h, c.d.w, N, len, 1};
     const bool m3 = c.math == LFT_MATH_BF16X3;
 #define LFT_LAUNCH_WG(NIV, TXV, GRID)                                                                                  \
@@ -521,7 +494,7 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
     RedTab red{};                                                    // every partial-sum producer registers a segment here
     size_t part_used = 0, part_peak = 0;
     static float dummy_base[64];
-    TrainCtx c{d, dry ? dummy_base : tape, T, WV, st, math, &red, &part_used, &part_peak, G, nullptr};
+    TrainCtx c{d, dry ? dummy_base : tape, T, WV, st, math, &red, &part_used, &part_peak, G};
     c.dry = dry;
     const ParamInfo pi = param_info(d.s);
     const long long N = d.ntok;

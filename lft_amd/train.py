@@ -72,19 +72,9 @@ def train_forward(ps, lr, A, s, tape=None, math="fp32"):
     return out, tape
 
 
-_side_streams = {}
-
-
-def side_stream(dev) -> torch.cuda.Stream:
-    """The per-device stream on which the weight-gradient kernels of a backward pass run beside the main chain."""
-    key = str(dev)
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=dev)
-    return _side_streams[key]
-
-
 def train_backward(ps, lr, tape, dout, A, s, grads=None, math="fp32", overlap=True):
-    """lft_train_backward: returns the flat gradient buffer (78 gradients back to back, state_dict order)."""
+    """lft_train_backward: returns the flat gradient buffer (78 gradients back to back, state_dict order).  `overlap` is accepted
+    and ignored since ABI 4: the pass runs on one stream (its gradient tensors share an arena)."""
     B, _, H, W = lr.shape
     h, w = H // A, W // A
     dev = lr.device
@@ -92,7 +82,7 @@ def train_backward(ps, lr, tape, dout, A, s, grads=None, math="fp32", overlap=Tr
         grads = torch.empty(grad_floats(s), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     _lib.check(_lib.lib().lft_train_backward(_ptr_array(ps), len(ps), lr.data_ptr(), tape.data_ptr(), dout.data_ptr(), grads.data_ptr(),
-                                             B, A, h, w, s, MATH[math], stream, side_stream(dev).cuda_stream if overlap else None),
+                                             B, A, h, w, s, MATH[math], stream, None),
                "lft_train_backward")
     return grads
 
@@ -125,7 +115,7 @@ def train_backward_buckets(ps, lr, tape, dout, A, s, grads, on_bucket, math="fp3
 
     cb = _lib.BUCKET_FN(trampoline)
     rc = _lib.lib().lft_train_backward_buckets(_ptr_array(ps), len(ps), lr.data_ptr(), tape.data_ptr(), dout.data_ptr(), grads.data_ptr(),
-                                               B, A, h, w, s, MATH[math], stream, side_stream(dev).cuda_stream if overlap else None,
+                                               B, A, h, w, s, MATH[math], stream, None,
                                                ctypes.cast(cb, ctypes.c_void_p), None)
     if err:
         raise err[0]
