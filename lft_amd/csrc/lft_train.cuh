@@ -635,17 +635,22 @@ LFT_DEV float dot8(const float (&a)[8], const float* b) {
     for (int c = 0; c < 8; ++c) s += a[c] * b[c];
     return s;
 }
+template <int VP> constexpr int kAngHS = VP * 8 + 8;     // floats per head of k_ang_attn's LDS tiles
 template <int VP, bool BWD>
 __global__ __launch_bounds__(8 * VP) void k_ang_attn(const float* __restrict__ QK, const float* __restrict__ Vv,
                                                      float* __restrict__ O, const float* __restrict__ dO,
                                                      float* __restrict__ dQK, float* __restrict__ dV, int V, int hw) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Ks = sm;                         // [8][VP][8]
-    float* Vs = Ks + 8 * VP * 8;
-    float* Qs = Vs + 8 * VP * 8;            // BWD only
-    float* Ds = Qs + 8 * VP * 8;            // BWD only: dO
-    float* St = Ds + 8 * VP * 8;            // BWD only: [8][VP][3] = m, 1/l, D
-    const int hd = threadIdx.x / VP, i = threadIdx.x % VP;
+    // thread = (view i, head hd) with the HEAD fastest: the 8 lanes of a view read its row's 8 head pieces = 256 contiguous
+    // bytes (view-fastest, every lane of a wave sat on a different row, 512 KB apart: 64 cache lines per load instruction).
+    // LDS tiles [8 heads][HS]: HS = VP * 8 + 8 floats, so that the 8 heads a wave reads together fall on disjoint banks.
+    constexpr int HS = kAngHS<VP>;
+    float* Ks = sm;                         // [8][VP][8] (+ 8 floats per head)
+    float* Vs = Ks + 8 * HS;
+    float* Qs = Vs + 8 * HS;                // BWD only
+    float* Ds = Qs + 8 * HS;                // BWD only: dO
+    float* St = Ds + 8 * HS;                // BWD only: [8][VP][3] = m, 1/l, D
+    const int hd = threadIdx.x & 7, i = threadIdx.x >> 3;
     const int b = blockIdx.x / hw, pix = blockIdx.x % hw;
     const bool act = i < V;
     const long long row = ((long long)b * V + min(i, V - 1)) * hw + pix;
@@ -653,25 +658,25 @@ __global__ __launch_bounds__(8 * VP) void k_ang_attn(const float* __restrict__ Q
     float q[8], tmp[8], dov[8];
     load8(QK + row * 128 + hd * 8, q);
     load8(QK + row * 128 + 64 + hd * 8, tmp);
-    store8(Ks + (hd * VP + i) * 8, tmp);
+    store8(Ks + hd * HS + i * 8, tmp);
     load8(Vv + row * 64 + hd * 8, tmp);
-    store8(Vs + (hd * VP + i) * 8, tmp);
+    store8(Vs + hd * HS + i * 8, tmp);
     if (BWD) {
-        store8(Qs + (hd * VP + i) * 8, q);
+        store8(Qs + hd * HS + i * 8, q);
         load8(dO + row * 64 + hd * 8, dov);
-        store8(Ds + (hd * VP + i) * 8, dov);
+        store8(Ds + hd * HS + i * 8, dov);
     }
     __syncthreads();
     float m = -INFINITY;
-    for (int j = 0; j < V; ++j) m = fmaxf(m, scale * dot8(q, Ks + (hd * VP + j) * 8));
+    for (int j = 0; j < V; ++j) m = fmaxf(m, scale * dot8(q, Ks + hd * HS + j * 8));
     float l = 0.0f;
     if (!BWD) {
         float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int j = 0; j < V; ++j) {
-            const float pj = expf(scale * dot8(q, Ks + (hd * VP + j) * 8) - m);
+            const float pj = expf(scale * dot8(q, Ks + hd * HS + j * 8) - m);
             l += pj;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) o[c] += pj * Vs[(hd * VP + j) * 8 + c];
+            for (int c = 0; c < 8; ++c) o[c] += pj * Vs[hd * HS + j * 8 + c];
         }
         const float inv = 1.0f / l;
 #pragma unroll
@@ -682,9 +687,9 @@ __global__ __launch_bounds__(8 * VP) void k_ang_attn(const float* __restrict__ Q
     // ---- backward, pass A (per query) ----
     float D = 0.0f, av[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = 0; j < V; ++j) {
-        const float* kj = Ks + (hd * VP + j) * 8;
+        const float* kj = Ks + hd * HS + j * 8;
         const float pj = expf(scale * dot8(q, kj) - m);
-        const float dp = dot8(dov, Vs + (hd * VP + j) * 8);
+        const float dp = dot8(dov, Vs + hd * HS + j * 8);
         l += pj; D += pj * dp;
 #pragma unroll
         for (int c = 0; c < 8; ++c) { av[c] += pj * dp * kj[c]; bv[c] += pj * kj[c]; }
@@ -700,10 +705,10 @@ __global__ __launch_bounds__(8 * VP) void k_ang_attn(const float* __restrict__ Q
     // ---- pass B (per key j = this thread's view) ----
     float kj[8], vj[8], dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { kj[c] = Ks[(hd * VP + i) * 8 + c]; vj[c] = Vs[(hd * VP + i) * 8 + c]; }
+    for (int c = 0; c < 8; ++c) { kj[c] = Ks[hd * HS + i * 8 + c]; vj[c] = Vs[hd * HS + i * 8 + c]; }
     for (int qi = 0; qi < V; ++qi) {
-        const float* qq = Qs + (hd * VP + qi) * 8;
-        const float* dd = Ds + (hd * VP + qi) * 8;
+        const float* qq = Qs + hd * HS + qi * 8;
+        const float* dd = Ds + hd * HS + qi * 8;
         const float pij = expf(scale * dot8(kj, qq) - St[(hd * VP + qi) * 3]) * St[(hd * VP + qi) * 3 + 1];
         const float ds = pij * (dot8(vj, dd) - St[(hd * VP + qi) * 3 + 2]);
 #pragma unroll

@@ -362,10 +362,10 @@ int ang_attn(const TrainCtx& c, const float* QK, const float* Vv, float* O, cons
     const int V = c.d.V, npix = c.d.B * c.d.hw;
     int rc;
     if (V <= 32) {
-        const size_t lds = BWD ? (size_t)(4 * 8 * 32 * 8 + 8 * 32 * 3) * 4 : (size_t)(2 * 8 * 32 * 8) * 4;
+        const size_t lds = BWD ? (size_t)(4 * 8 * kAngHS<32> + 8 * 32 * 3) * 4 : (size_t)(2 * 8 * kAngHS<32>) * 4;
         k_ang_attn<32, BWD><<<npix, 256, lds, c.st>>>(QK, Vv, O, dO, dQK, dV, V, c.d.hw);
     } else {
-        const size_t lds = BWD ? (size_t)(4 * 8 * 128 * 8 + 8 * 128 * 3) * 4 : (size_t)(2 * 8 * 128 * 8) * 4;
+        const size_t lds = BWD ? (size_t)(4 * 8 * kAngHS<128> + 8 * 128 * 3) * 4 : (size_t)(2 * 8 * kAngHS<128>) * 4;
         if ((rc = allow_lds(k_ang_attn<128, BWD>, lds, "k_ang_attn"))) return rc;
         k_ang_attn<128, BWD><<<npix, 1024, lds, c.st>>>(QK, Vv, O, dO, dQK, dV, V, c.d.hw);
     }
