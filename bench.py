@@ -25,6 +25,7 @@ Prints ONE JSON line on rank 0 with the extra objects
                  `meets_tolerance` / `value_within_tolerance` say whether `value` itself is inside 1e-3 and what the fastest path
                  inside it delivers.
   latency_path : the same workload strictly one step after the other (one captured forward, nothing in flight beside it).
+  sustained_path : the headline's step over a timed region of >= 3 000 steps (> 1 s): the rate after the card's power management has settled.
   per_rank_ms  : every rank's own ms per step (a straggler shows here; `ms_per_step` is the maximum).
   train        : BASELINE configs[2] on this GPU (A5, 2x, batch 8, Adam; one process = no all-reduce partner): ms/step, patches/s.
   cpu_baseline : the CPU oracle (a port of the reference's operator sequence, oracle/lft_oracle.py) timed on
@@ -199,11 +200,19 @@ def make_step(net, lr, args, inflight: int):
     return g, g
 
 
+SETTLE_STEPS = 100        # untimed steps in front of --warmup (about 45 ms of load), see timed_protocol
+
+
 def timed_protocol(step, lr, args, sync):
-    """THE timing protocol, shared by the headline, the parity path and the latency path: 30 untimed settle steps (set-up:
-    clocks and caches), --warmup untimed steps, then exactly --steps steps bracketed by barrier + device synchronisation."""
+    """THE timing protocol, shared by the headline, the parity path and the latency path: SETTLE_STEPS untimed settle steps,
+    --warmup untimed steps, then exactly --steps steps bracketed by barrier + device synchronisation.
+    Why 100 settle steps: the card's clocks need tens of milliseconds of load to come up.  Measured with the driver's
+    --steps 20 --warmup 5 on one box, four interleaved repetitions each (gpurun_out/r4k): 30 settle steps 8 640 - 9 000
+    patches/s, 100: 9 140 - 9 510, 300: 9 270 - 9 330 -- and 1 000: 8 670 - 8 820, i.e. on THAT box the card's power management
+    took the clocks down again after ~0.4 s of load.  Another box held 9 900 over a 3 000-step region (gpurun_out/r4l).  The
+    JSON therefore also carries sustained_path: the same step timed over more than a second."""
     with torch.no_grad():
-        for _ in range(30):
+        for _ in range(SETTLE_STEPS):
             step(lr)
         torch.cuda.synchronize()
         for _ in range(args.warmup):
@@ -245,7 +254,7 @@ def parity_path(args, dev, lr, head_net):
         outs["headline"] = head_net(lr[:1]).float().cpu()
     res = dict(timed["fp16"], precision="fp16 (v_mfma_f32_32x32x16_f16, fp16 storage, fp32 accumulation / softmax / LayerNorm)",
                tolerance="max|out - ref| <= 1e-3 * max|ref| (BASELINE.json north_star; the output lives in [0, 1], so this is an absolute bound)",
-               protocol="as the headline: 30 settle steps, --warmup, --steps, same steps in flight",
+               protocol=f"as the headline: {SETTLE_STEPS} settle steps, --warmup, --steps, same steps in flight",
                overflow_check="status words read after the timed region: clear",
                exact_fp32=dict(timed["fp32"], precision="fp32 (v_mfma_f32_32x32x2_f32, fp32 storage)"))
     return res, outs
@@ -631,6 +640,24 @@ def main():
             result["latency_path"] = {"value": args.batch * args.steps / dt1, "unit": "patches/s", "ms_per_step": dt1 / args.steps * 1e3,
                                       "steps_in_flight": 1, "note": "one captured forward replayed strictly one after the other: ms_per_step is the latency of a batch"}
             del step1, owner1
+        if extras and not args.no_graph:
+            # the sustained rate: a timed region long enough (>= 1.2 s) for the card's power management to have settled; the
+            # headline's short region sits in the window between clock ramp-up and that settling (timed_protocol)
+            note("timing a long region (sustained rate) ...")
+            n_long = max(args.steps, 3000)
+            step2, owner2 = make_step(net, lr, args, args.inflight)
+            with torch.no_grad():
+                for _ in range(SETTLE_STEPS):
+                    step2(lr)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_long):
+                    step2(lr)
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t0
+            result["sustained_path"] = {"value": args.batch * n_long / dt2, "unit": "patches/s", "steps": n_long, "ms_per_step": dt2 / n_long * 1e3,
+                                        "note": "same step as the headline, timed over a region of more than a second"}
+            del step2, owner2
         if extras and args.precision == "bf16":
             note("timing the fp16 and exact-fp32 parity paths ...")
             result["parity_path"], outs = parity_path(args, dev, lr, net)
