@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 3) void k_linr(const LinP p) {
 // MFMA with k = token: A[m = o][k] = dY[t0 + k][o], B[k][n = i] = X[shift(t0 + k)][i]; both operands are read
 // straight from the channels-last tensors (lanes = consecutive channels of one token: 128-byte segments).
 // A wave owns one 32-row block of dY channels, one tap, NI 32-column blocks of X channels and one token chunk.
-// grid: x = chunk, y = (o tile, i group), z = tap row (3x3) or 1.   k_reduce_all then sums the chunks in a fixed order.
+// grid: 1-D over (chunk, (o tile, i group), tap row), see the kernel.   k_reduce_all then sums the chunks in a fixed order.
 // ------------------------------------------------------------------------------------------
 struct WgP {
     const float* dY; int ldy;
@@ -300,6 +300,7 @@ struct WgP {
     int h, w;
     long long N, chunk_len;           // chunk_len % 64 == 0: four waves x 16-token k-steps
     int igroups;
+    int nch, gy;                      // token chunks; workgroups per chunk and tap row (output tiles x input groups)
 };
 
 // TX = 3: the wave owns a whole ROW of taps (dy fixed by blockIdx.z, dx = -1, 0, +1): the dY fragment is loaded (and
@@ -311,12 +312,20 @@ __global__ __launch_bounds__(256, TX == 3 ? 2 : 3) void k_wgrad(const WgP p) {
     extern __shared__ __attribute__((aligned(16))) float wred[];        // [3 waves][TX * NI tiles][16][64]
     const int lane = threadIdx.x & 63, r = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ot = blockIdx.y / p.igroups, ig = blockIdx.y % p.igroups;
+    // 1-D grid: the gy (x 3 tap rows) workgroups that read the SAME token chunk get workgroup ids 8 apart -- ids are dealt round
+    // robin to the 8 XCDs, so they run on one XCD at about the same time and the chunk's second .. last reader hits in its L2
+    // (as grid (chunk, tile, tap row) they were a whole launch apart: every tile and tap row re-read its operands from HBM)
+    const int per = p.gy * (TX == 3 ? 3 : 1);
+    const int grp = (int)blockIdx.x / (8 * per), rem = (int)blockIdx.x % (8 * per);
+    const int chunk = grp * 8 + (rem & 7), sub_id = rem >> 3;
+    if (chunk >= p.nch) return;                                         // (whole workgroup: the last group of 8 may be short)
+    const int by = sub_id % p.gy, bz = sub_id / p.gy;
+    const int ot = by / p.igroups, ig = by % p.igroups;
     const int o0 = ot * 32, i0 = ig * NI * 32;
     const long long sub = p.chunk_len >> 2;                              // chunk_len % 64 == 0
-    const long long ta = (long long)blockIdx.x * p.chunk_len + wave * sub, tb = min(ta + sub, p.N);
+    const long long ta = (long long)chunk * p.chunk_len + wave * sub, tb = min(ta + sub, p.N);
     const int hw = p.h * p.w;
-    const int dy = TX == 3 ? (int)blockIdx.z - 1 : 0;
+    const int dy = TX == 3 ? bz - 1 : 0;
     f32x16 acc[TX][NI];
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx) zero_acc<NI>(acc[tx]);
@@ -393,8 +402,8 @@ __global__ __launch_bounds__(256, TX == 3 ? 2 : 3) void k_wgrad(const WgP p) {
                 for (int i = 0; i < 16; ++i) acc[tx][ni][i] += wred[((w2 * TX * NI + tx * NI + ni) * 16 + i) * 64 + lane];
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx) {
-        const int tap = TX == 3 ? (int)blockIdx.z * 3 + tx : 0;
-        float* dst = p.part + (long long)blockIdx.x * p.wsize + (size_t)tap * p.st;
+        const int tap = TX == 3 ? bz * 3 + tx : 0;
+        float* dst = p.part + (long long)chunk * p.wsize + (size_t)tap * p.st;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll

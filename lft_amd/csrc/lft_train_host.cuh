@@ -278,26 +278,24 @@ int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, in
     if ((rc = part_take(c, (size_t)nch * wsize, &poff))) return rc;
     if (c.dry) return 0;
     hipStream_t ws = c.st;
-    WgP p{dY, Co, X, Ci, c.F(c.T.part) + poff, wsize, Ci * taps, taps, 1, Co, Ci, taps, c.d.h, c.d.w, N, len, 1};
+    WgP p{dY, Co, X, Ci, c.F(c.T.part) + poff, wsize, Ci * taps, taps, 1, Co, Ci, taps, c.d.h, c.d.w, N, len, 1, nch, 1};
     const bool m3 = c.math == LFT_MATH_BF16X3;
-#define LFT_LAUNCH_WG(NIV, TXV, GRID)                                                                                  \
+#define LFT_LAUNCH_WG(NIV, TXV)                                                                                        \
     do {                                                                                                               \
         const size_t lds = (size_t)3 * TXV * NIV * 16 * 64 * sizeof(float);                                            \
-        if (m3) { if ((rc = allow_lds(k_wgrad<NIV, true, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, true, TXV><<<GRID, 256, lds, ws>>>(p); }   \
-        else { if ((rc = allow_lds(k_wgrad<NIV, false, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, false, TXV><<<GRID, 256, lds, ws>>>(p); }    \
+        const dim3 g((unsigned)((nch + 7) / 8 * 8 * p.gy * TXV));                                                       \
+        if (m3) { if ((rc = allow_lds(k_wgrad<NIV, true, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, true, TXV><<<g, 256, lds, ws>>>(p); }   \
+        else { if ((rc = allow_lds(k_wgrad<NIV, false, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, false, TXV><<<g, 256, lds, ws>>>(p); }    \
     } while (0)
     if (taps == 9) {
-        p.igroups = 1;
-        const dim3 g((unsigned)nch, (unsigned)(Co / 32), 3u);
-        LFT_LAUNCH_WG(2, 3, g);
+        p.igroups = 1; p.gy = Co / 32;
+        LFT_LAUNCH_WG(2, 3);
     } else if (Ci % 128 == 0) {
-        p.igroups = Ci / 128;
-        const dim3 g((unsigned)nch, (unsigned)(Co / 32 * p.igroups), 1u);
-        LFT_LAUNCH_WG(4, 1, g);
+        p.igroups = Ci / 128; p.gy = Co / 32 * p.igroups;
+        LFT_LAUNCH_WG(4, 1);
     } else {
-        p.igroups = Ci / 64;
-        const dim3 g((unsigned)nch, (unsigned)(Co / 32 * p.igroups), 1u);
-        LFT_LAUNCH_WG(2, 1, g);
+        p.igroups = Ci / 64; p.gy = Co / 32 * p.igroups;
+        LFT_LAUNCH_WG(2, 1);
     }
 #undef LFT_LAUNCH_WG
     LFT_LAUNCH_OK(prof_name("k_wgrad", "k_wgrad:%dx%d%s", Co, Ci, taps == 9 ? " 3x3" : ""));
