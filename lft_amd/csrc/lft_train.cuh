@@ -88,6 +88,7 @@ struct LinP {
     int taps, flip, act;              // act: 0 none, 1 relu, 2 leaky relu 0.2
     int h, w;
     long long N;
+    int gy;                           // k_linr: output groups (workgroups per 128 tokens)
 };
 
 // TILED (plain Linears at small batch): the 32 input rows of a wave, consecutive in memory, are fetched in coalesced
@@ -191,11 +192,17 @@ __global__ __launch_bounds__(256, 3) void k_linr(const LinP p) {
     const int lane = threadIdx.x & 63, r = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char* scr = lds + 2 * CHUNK + wave * SCR;
-    const long long t0w = ((long long)blockIdx.x * 4 + wave) * 32;
+    // 1-D grid: the p.gy workgroups (output groups) that read the same 128 tokens get ids 8 apart = the same XCD at about the
+    // same time: the second reader of the rows hits in that XCD's L2 (as grid (tokens, group) they were a launch apart)
+    const int grp8 = (int)blockIdx.x / (8 * p.gy), rem = (int)blockIdx.x % (8 * p.gy);
+    const long long tile = (long long)grp8 * 8 + (rem & 7);
+    const int by = rem >> 3;
+    const long long t0w = (tile * 4 + wave) * 32;
+    if (tile * 128 >= p.N) return;                                       // (whole workgroup: the last group of 8 may be short)
     const bool active = t0w < p.N;                                       // a wave past the end still runs the ring protocol (barriers, DMA share)
     const long long t0 = active ? t0w : 0;
     const int nvalid = active ? (int)min((long long)32, p.N - t0) : 0;
-    const int otl = blockIdx.y * NT, o0 = otl * 32, ot0 = p.ot0 + otl;
+    const int otl = by * NT, o0 = otl * 32, ot0 = p.ot0 + otl;
     const long long t = min(t0 + r, p.N - 1);
     const int hw = p.h * p.w;
     const int pix = (int)(t % hw), y = pix / p.w, x = pix - y * p.w;

@@ -213,7 +213,7 @@ int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int l
     const WView& v = c.W.v[view];
     if (nOT <= 0) nOT = v.OT;
     if ((v.taps != 1 && (ot0 || nOT != v.OT))) return fail(LFT_ERR_ARG, "run_lin: bad tile block (view %d)", view);
-    LinP p{X, ldx, c.F(c.T.wp) + v.frag0 * 512, v.OT, v.KS, ot0, R, ldr, Y, ldy, M, ldy, mact, v.taps, flip, act, c.d.h, c.d.w, N};
+    LinP p{X, ldx, c.F(c.T.wp) + v.frag0 * 512, v.OT, v.KS, ot0, R, ldr, Y, ldy, M, ldy, mact, v.taps, flip, act, c.d.h, c.d.w, N, 1};
     const unsigned gx = (unsigned)((N + 127) / 128);
     // output tiles per wave: 4 when that still gives the chip >= 2 waves per SIMD, fewer (more, thinner waves) for small N
     const long long tiles = (N + 31) / 32;
@@ -233,8 +233,10 @@ int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int l
         else { if (tiled) k_lin<NTV, false, true><<<g, 256, 0, c.st>>>(p); else k_lin<NTV, false, false><<<g, 256, 0, c.st>>>(p); }     \
     } while (0)
     if (ring) {
-        if (nt == 4) { if (m3) k_linr<4, true><<<g, 256, 0, c.st>>>(p); else k_linr<4, false><<<g, 256, 0, c.st>>>(p); }
-        else { if (m3) k_linr<2, true><<<g, 256, 0, c.st>>>(p); else k_linr<2, false><<<g, 256, 0, c.st>>>(p); }
+        p.gy = nOT / nt;
+        const dim3 g1((unsigned)((gx + 7) / 8 * 8 * p.gy));
+        if (nt == 4) { if (m3) k_linr<4, true><<<g1, 256, 0, c.st>>>(p); else k_linr<4, false><<<g1, 256, 0, c.st>>>(p); }
+        else { if (m3) k_linr<2, true><<<g1, 256, 0, c.st>>>(p); else k_linr<2, false><<<g1, 256, 0, c.st>>>(p); }
     } else if (nt == 4) LFT_LAUNCH_LIN(4); else if (nt == 2) LFT_LAUNCH_LIN(2); else LFT_LAUNCH_LIN(1);
 #undef LFT_LAUNCH_LIN
     LFT_LAUNCH_OK(prof_name("k_lin", "k_lin:%d>%d%s%s%s", v.KS * 16, nOT * 32, v.taps == 9 ? " 3x3" : "", R ? " +R" : "", M ? " *M" : ""));
