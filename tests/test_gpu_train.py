@@ -399,15 +399,18 @@ def test_fit_trains_and_writes_reference_format_checkpoints(tmp_path):
         assert torch.equal(fresh(lr), net.eval()(lr))
 
 
+@pytest.mark.parametrize("hw", [(32, 32), (33, 35)], ids=["32x32", "33x35_ragged"])
 @pytest.mark.parametrize("math", MATHS)
-def test_full_size_backward_properties_cfg3(math):
+def test_full_size_backward_properties_cfg3(math, hw):
     """BASELINE configs[2] shape (A5, 2x, 32x32 LR views), where autograd over the CPU oracle takes minutes: properties
     that hold at any size instead.  For a fixed forward the backward pass is linear in d loss / d out, and patches never
     interact, so (i) grads(a*g1 + g2) = a*grads(g1) + grads(g2), (ii) the gradient of a 3-patch batch is the sum of the
     per-patch gradients; and the forward-with-tape must agree with the fused inference kernels.  Three patches are 76 800 tokens:
     the batch runs the ring-fed GEMM kernel (k_linr, above 65 536 tokens), the single patches the direct one (k_lin) -- (ii) and
-    the forward comparison hold the two against each other and against the inference path."""
-    A, s, B, h, w = 5, 2, 3, 32, 32
+    the forward comparison hold the two against each other and against the inference path.  33 x 35 views: 86 625 tokens, not
+    a multiple of 32 -- partial tiles, waves past the end that only serve the ring, 32-token tiles that straddle image rows."""
+    A, s, B = 5, 2, 3
+    h, w = hw
     tol = {"fp32": 2e-5, "bf16x3": 1e-4}[math]
     sd_np = deterministic_state(64, s, seed=1, flavor="stress")
     names = [n for n, _, _ in param_table(64, s)]
