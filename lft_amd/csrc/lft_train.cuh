@@ -183,7 +183,27 @@ __global__ __launch_bounds__(256, 3) void k_lin(const LinP p) {
 // and after the last k-step (activation-derivative tile, output tile); slot 2 is first written by the DMA behind barrier 0.
 // Requires: the call's output block is one packed group (NT == its tile count, first tile a multiple of 4); taps == 9: OT == NT.
 // ------------------------------------------------------------------------------------------
-template <int NT, bool M3>
+// One token to the left / right inside a wave's 32-token row (lanes 0-31 and 32-63 hold the two k-halves of the same tokens):
+// DIR = +1: lane r takes lane r + 1 (v_mov_dpp wave_shl:1), DIR = -1: lane r - 1 (wave_shr:1); the row's first / last token takes 0
+// (the lane the shift would pull across the two halves, or from outside the wave).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int DIR> LFT_DEV u32x4_t lane_shift1_u(u32x4_t u, bool edge) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = __builtin_amdgcn_update_dpp(0, (int)u[i], DIR > 0 ? 0x130 : 0x138, 0xf, 0xf, true);
+        u[i] = edge ? 0u : (unsigned)s;
+    }
+    return u;
+}
+template <int DIR> LFT_DEV bf16x8 lane_shift1(bf16x8 v, bool edge) { return __builtin_bit_cast(bf16x8, lane_shift1_u<DIR>(__builtin_bit_cast(u32x4_t, v), edge)); }
+template <int DIR> LFT_DEV f32x4 lane_shift1(f32x4 v, bool edge) { return __builtin_bit_cast(f32x4, lane_shift1_u<DIR>(__builtin_bit_cast(u32x4_t, v), edge)); }
+
+// KS3 > 0 (= KS, 4 or 8): a per-view 3x3 convolution on 32-wide views, where a wave's 32 tokens are ONE image row.  The KS row
+// fragments of an input row (dy) are loaded ONCE and serve its three taps: the neighbours to the left and right are the same
+// registers one lane over (lane_shift1), the image's left / right border is the shift's zero.  Input rows come from L2 three
+// times instead of nine and the split into bf16 pairs is done once per row fragment instead of once per tap -- in the SAME step
+// order (tap row, tap column, k-step) and with the same operand values as the generic form, so the results are bit-identical.
+template <int NT, bool M3, int KS3 = 0>
 __global__ __launch_bounds__(256, 3) void k_linr(const LinP p) {
     constexpr int CHUNK = NT * 2048, PPW = NT / 2;                        // bytes of weights per k-step; 1 KiB pieces per wave and chunk
     constexpr int SCR = TileIO<NT, float>::BYTES;
@@ -221,6 +241,64 @@ __global__ __launch_bounds__(256, 3) void k_linr(const LinP p) {
     f32x16 acc[NT];
     if (p.R) load_tile<NT, float>(p.R + t0 * p.ldr + o0, nvalid, lane, acc, scr, (size_t)p.ldr * 4);
     else zero_acc<NT>(acc);
+    if constexpr (KS3 > 0) {
+        const bool lane_ok = t0w + r < p.N, e_lo = r == 0, e_hi = r == 31;
+        int cs = 0, slot = 0;
+        for (int dyi = 0; dyi < 3; ++dyi) {
+            const int dy = p.flip ? 1 - dyi : dyi - 1;
+            const bool okr = lane_ok && (y + dy >= 0) && (y + dy < p.h);
+            const float* row = p.X + (okr ? t + dy * p.w : t) * p.ldx + 8 * kh;
+            Frag<float> xr[KS3];
+#pragma unroll
+            for (int ks = 0; ks < KS3; ++ks) xr[ks] = load_row8(row + 16 * ks, true, 0.0f);
+            Frag<float> xf[M3 ? 1 : KS3];
+            Frag2 x2[M3 ? KS3 : 1];
+#pragma unroll
+            for (int ks = 0; ks < KS3; ++ks) {
+                const Frag<float> z = okr ? xr[ks] : frag_zero(0.0f);
+                if constexpr (M3) x2[ks] = split_frag(z); else xf[ks] = z;
+            }
+            for (int dxi = 0; dxi < 3; ++dxi) {
+                const int dx = p.flip ? 1 - dxi : dxi - 1;               // uniform
+#pragma unroll
+                for (int ks = 0; ks < KS3; ++ks) {
+                    // this wave's pieces of chunk cs have landed (only those of chunk cs + 1 may still be in flight: the counted wait
+                    // of WRing), then the barrier publishes the chunk and retires chunk cs - 1
+                    wait_vmcnt(cs + 1 < S ? PPW : 0);
+                    wg_barrier_keep_vm();
+                    issue_w(cs + 2, slot == 0 ? 2 : slot - 1);
+                    const char* base = lds + slot * CHUNK + lane * 16;
+                    Frag2 b2;
+                    Frag<float> b;
+                    if constexpr (M3) {
+                        b2 = x2[ks];
+                        if (dx > 0) { b2.hi.v = lane_shift1<1>(x2[ks].hi.v, e_hi); b2.lo.v = lane_shift1<1>(x2[ks].lo.v, e_hi); }
+                        else if (dx < 0) { b2.hi.v = lane_shift1<-1>(x2[ks].hi.v, e_lo); b2.lo.v = lane_shift1<-1>(x2[ks].lo.v, e_lo); }
+                    } else {
+                        b = xf[ks];
+                        if (dx > 0) { b.lo = lane_shift1<1>(xf[ks].lo, e_hi); b.hi = lane_shift1<1>(xf[ks].hi, e_hi); }
+                        else if (dx < 0) { b.lo = lane_shift1<-1>(xf[ks].lo, e_lo); b.hi = lane_shift1<-1>(xf[ks].hi, e_lo); }
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if constexpr (M3) {
+                            Frag2 w2;
+                            w2.hi.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * 2048));
+                            w2.lo.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * 2048 + 1024));
+                            mma3(w2, b2, acc[nt]);
+                        } else {
+                            Frag<float> wf;
+                            wf.lo = __builtin_bit_cast(f32x4, load_raw16(base + nt * 2048));
+                            wf.hi = __builtin_bit_cast(f32x4, load_raw16(base + nt * 2048 + 1024));
+                            mma(wf, b, acc[nt]);
+                        }
+                    }
+                    ++cs;
+                    slot = slot == 2 ? 0 : slot + 1;
+                }
+            }
+        }
+    } else {
     // cursor of the next row load: (tap, k-step); past the last k-step it stays there (one redundant, cached reload)
     int ctap = 0, cks = 0;
     auto load_x = [&](bool& ok) -> Frag<float> {                         // raw rows; zeroed by `ok` where they are consumed (a select here would pull the wait up to here)
@@ -268,6 +346,7 @@ __global__ __launch_bounds__(256, 3) void k_linr(const LinP p) {
         step(xa, oka);
         xa = load_x(oka);
         step(xb, okb);
+    }
     }
     wg_barrier_keep_vm();                                                // every wave is done with the ring: slot 2 is scratch again
     if (p.act) {

@@ -235,8 +235,12 @@ int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int l
     if (ring) {
         p.gy = nOT / nt;
         const dim3 g1((unsigned)((gx + 7) / 8 * 8 * p.gy));
-        if (nt == 4) { if (m3) k_linr<4, true><<<g1, 256, 0, c.st>>>(p); else k_linr<4, false><<<g1, 256, 0, c.st>>>(p); }
-        else { if (m3) k_linr<2, true><<<g1, 256, 0, c.st>>>(p); else k_linr<2, false><<<g1, 256, 0, c.st>>>(p); }
+        // 3x3 on 32-wide views (a wave's 32 tokens = one image row): the row fragments are loaded once per tap row (k_linr<.., KS>)
+        const int ks3 = (v.taps == 9 && c.d.w == 32 && (v.KS == 4 || v.KS == 8)) ? v.KS : 0;
+#define LFT_LAUNCH_R(NTV, KSV) do { if (m3) k_linr<NTV, true, KSV><<<g1, 256, 0, c.st>>>(p); else k_linr<NTV, false, KSV><<<g1, 256, 0, c.st>>>(p); } while (0)
+        if (nt == 4) { if (ks3 == 4) LFT_LAUNCH_R(4, 4); else LFT_LAUNCH_R(4, 0); }     // (no 3x3 view has 128 inputs and 128 outputs)
+        else { if (ks3 == 4) LFT_LAUNCH_R(2, 4); else if (ks3 == 8) LFT_LAUNCH_R(2, 8); else LFT_LAUNCH_R(2, 0); }
+#undef LFT_LAUNCH_R
     } else if (nt == 4) LFT_LAUNCH_LIN(4); else if (nt == 2) LFT_LAUNCH_LIN(2); else LFT_LAUNCH_LIN(1);
 #undef LFT_LAUNCH_LIN
     LFT_LAUNCH_OK(prof_name("k_lin", "k_lin:%d>%d%s%s%s", v.KS * 16, nOT * 32, v.taps == 9 ? " 3x3" : "", R ? " +R" : "", M ? " *M" : ""));
