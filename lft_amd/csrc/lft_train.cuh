@@ -427,6 +427,67 @@ __global__ __launch_bounds__(256, TX == 3 ? 2 : 3) void k_wgrad(const WgP p) {
     unsigned vy = ((unsigned)(8 * kh) * p.ldy + r) * 4u, vx = ((unsigned)(8 * kh + pre) * p.ldx + r) * 4u;
     int rl = 8 * kh, ys = 0, xs = 0;
     if constexpr (TX == 3) { const int pix = (int)((ta + 8 * kh) % hw); ys = pix / p.w; xs = pix - ys * p.w; }
+    // 3x3 on 32-wide views: a 16-token step lies in one half of ONE image row, every step is full (N, the chunk and the wave's
+    // share are multiples of 16).  A lane's three tap fragments X[t + j - 1], X[t + j], X[t + j + 1] (j = 0..7) are ten values:
+    // eight centre ones, a left and a right neighbour -- 10 loads instead of 24, and in split mode each value is split ONCE and
+    // the three fragments are two packings of the same bf16 pairs (even pairs (c0,c1).. for the centre tap, odd pairs
+    // (L,c0),(c1,c2)..,(c7,R) for the other two).  Same values, same MFMA order as the general form below: bit-identical.
+    bool fast3 = false;
+    if constexpr (TX == 3) fast3 = p.w == 32 && nsub % 16 == 0 && ta % 16 == 0;
+    if (fast3) {
+        if constexpr (TX == 3) {
+            const int pix0 = (int)(ta % hw);
+            int yw = pix0 / 32, xb = pix0 % 32;                             // wave-uniform: image row and half (0 / 16) of the step
+            for (int step = 0; step * 16 < nsub; ++step) {
+                const bool okrow = (yw + dy >= 0) && (yw + dy < p.h);       // uniform
+                const bool okl = okrow && (xb + 8 * kh > 0), okr = okrow && (xb + 8 * kh + 8 < 32);
+                Frag<float> a;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float av = *reinterpret_cast<const float*>(ya + vy + (unsigned)(j * p.ldy) * 4u);
+                    if (j < 4) a.lo[j] = av; else a.hi[j - 4] = av;
+                }
+                float v[NI][10];                                            // [0] = left neighbour, [1..8] = centre, [9] = right neighbour
+#pragma unroll
+                for (int e = 0; e < 10; ++e) {
+                    const bool ok = e == 0 ? okl : e == 9 ? okr : okrow;
+                    const float* xr = reinterpret_cast<const float*>(xa + (ok ? vx + (unsigned)((e - 1 + dy * 32) * p.ldx) * 4u : safe_x));
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) { const float t = xr[32 * ni]; v[ni][e] = ok ? t : 0.0f; }
+                }
+                vy += 16u * p.ldy * 4u; vx += 16u * p.ldx * 4u;
+                xb += 16;
+                if (xb == 32) { xb = 0; if (++yw == p.h) yw = 0; }
+                if constexpr (M3) {
+                    const Frag2 a2 = split_frag(a);
+                    bf16_t hi[NI][10], lo[NI][10];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int e = 0; e < 10; ++e) { hi[ni][e] = (bf16_t)v[ni][e]; lo[ni][e] = (bf16_t)(v[ni][e] - (float)hi[ni][e]); }
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            Frag2 b2;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { b2.hi.v[j] = hi[ni][j + tx]; b2.lo.v[j] = lo[ni][j + tx]; }
+                            mma3(a2, b2, acc[tx][ni]);
+                        }
+                } else {
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            Frag<float> b;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { if (j < 4) b.lo[j] = v[ni][j + tx]; else b.hi[j - 4] = v[ni][j + tx]; }
+                            mma(a, b, acc[tx][ni]);
+                        }
+                }
+            }
+        }
+    } else
     for (int step = 0; step * 16 < nsub; ++step) {
         Frag<float> a, b[TX][NI];
         int y = ys, x = xs;
