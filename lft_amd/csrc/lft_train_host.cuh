@@ -373,7 +373,7 @@ int ang_attn(const TrainCtx& c, const float* QK, const float* Vv, float* O, cons
         if ((rc = allow_lds(k_ang_attn<128, BWD>, lds, "k_ang_attn"))) return rc;
         k_ang_attn<128, BWD><<<npix, 1024, lds, c.st>>>(QK, Vv, O, dO, dQK, dV, V, c.d.hw);
     }
-    LFT_LAUNCH_OK("k_ang_attn");
+    LFT_LAUNCH_OK(prof_name("k_ang_attn", "k_ang_attn:%s", BWD ? "backward" : "forward"));
     return 0;
 }
 
@@ -385,7 +385,7 @@ int win_attn(const TrainCtx& c, const float* Q, const float* K, const float* V, 
     int rc;
     if ((rc = allow_lds(k_win_attn_lds<MODE>, kWaLds, "k_win_attn_lds"))) return rc;
     k_win_attn_lds<MODE><<<dim3(tiles, 4), 256, kWaLds, c.st>>>(Q, K, V, O, dO, dQ, dK, dV, c.F(c.T.stats), d.h, d.w, 256);
-    LFT_LAUNCH_OK("k_win_attn_lds");
+    LFT_LAUNCH_OK(prof_name("k_win_attn_lds", "k_win_attn_lds:%s", MODE == 0 ? "forward" : MODE == 1 ? "bwd A (dQ)" : "bwd B (dK dV)"));
     return 0;
 }
 
