@@ -99,6 +99,9 @@ def test_training_and_metrics_size_queries_and_argument_errors():
     assert T.grad_floats(2) == sum(int(np.prod(s)) for _, s, _ in param_table(64, 2)) == 1_114_240
     assert T.grad_floats(4) == 1_163_392
     assert T.tape_bytes(2, 5, 32, 32, 2) > 2 * T.tape_bytes(1, 5, 32, 32, 2) * 0.9
+    # the backward pass's gradient tensors share an arena and the partial sums are reduced per layer (both sized by a dry run of
+    # the pass): BASELINE configs[2] at 8 patches per step stays under 1 GiB per patch (round 2: 1.94)
+    assert T.tape_bytes(8, 5, 32, 32, 2) <= 8 * 2**30
     L = _lib.lib()
     n = ctypes.c_size_t(0)
     assert L.lft_train_grad_floats(3, ctypes.byref(n)) == -2                            # LFT_ERR_SHAPE
