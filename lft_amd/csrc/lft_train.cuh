@@ -823,16 +823,36 @@ __global__ __launch_bounds__(8 * VP) void k_ang_attn(const float* __restrict__ Q
         store8(Ds + hd * HS + i * 8, dov);
     }
     __syncthreads();
+    // scores once, kept in registers (a second pass that recomputed the dot products was a quarter of the kernel's vector work);
+    // the loop over the VP possible keys is unrolled so that the array is indexed by constants, keys >= V are skipped uniformly
+    float sc[VP <= 32 ? VP : 1];
     float m = -INFINITY;
-    for (int j = 0; j < V; ++j) m = fmaxf(m, scale * dot8(q, Ks + hd * HS + j * 8));
+    if constexpr (VP <= 32) {
+#pragma unroll
+        for (int j = 0; j < VP; ++j)
+            if (j < V) { sc[j] = dot8(q, Ks + hd * HS + j * 8); m = fmaxf(m, scale * sc[j]); }   // the raw dot product: the expressions below are the two-pass form's, bit for bit
+    } else {
+        for (int j = 0; j < V; ++j) m = fmaxf(m, scale * dot8(q, Ks + hd * HS + j * 8));
+    }
     float l = 0.0f;
     if (!BWD) {
         float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int j = 0; j < V; ++j) {
-            const float pj = expf(scale * dot8(q, Ks + hd * HS + j * 8) - m);
-            l += pj;
+        if constexpr (VP <= 32) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) o[c] += pj * Vs[hd * HS + j * 8 + c];
+            for (int j = 0; j < VP; ++j)
+                if (j < V) {
+                    const float pj = expf(scale * sc[j] - m);
+                    l += pj;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) o[c] += pj * Vs[hd * HS + j * 8 + c];
+                }
+        } else {
+            for (int j = 0; j < V; ++j) {
+                const float pj = expf(scale * dot8(q, Ks + hd * HS + j * 8) - m);
+                l += pj;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] += pj * Vs[hd * HS + j * 8 + c];
+            }
         }
         const float inv = 1.0f / l;
 #pragma unroll
@@ -842,13 +862,19 @@ __global__ __launch_bounds__(8 * VP) void k_ang_attn(const float* __restrict__ Q
     }
     // ---- backward, pass A (per query) ----
     float D = 0.0f, av[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int j = 0; j < V; ++j) {
+    auto passA = [&](int j, float pj) {
         const float* kj = Ks + hd * HS + j * 8;
-        const float pj = expf(scale * dot8(q, kj) - m);
         const float dp = dot8(dov, Vs + hd * HS + j * 8);
         l += pj; D += pj * dp;
 #pragma unroll
         for (int c = 0; c < 8; ++c) { av[c] += pj * dp * kj[c]; bv[c] += pj * kj[c]; }
+    };
+    if constexpr (VP <= 32) {
+#pragma unroll
+        for (int j = 0; j < VP; ++j)
+            if (j < V) passA(j, expf(scale * sc[j] - m));
+    } else {
+        for (int j = 0; j < V; ++j) passA(j, expf(scale * dot8(q, Ks + hd * HS + j * 8) - m));
     }
     const float inv = 1.0f / l;
     D *= inv;
