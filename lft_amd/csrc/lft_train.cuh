@@ -1160,14 +1160,16 @@ __global__ void k_upm_fold(const float* __restrict__ dM, float* __restrict__ dw3
 __global__ __launch_bounds__(256) void k_conv0_wgrad(const float* __restrict__ dX0, const float* __restrict__ lr,
                                                      float* __restrict__ part, int B, int A, int h, int w, long long toks_per_wave) {
     const int c = threadIdx.x & 63, V = A * A;
-    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long wv = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long N = (long long)B * V * h * w;
     float dw[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) dw[t] = 0.0f;
     const long long t0 = wv * toks_per_wave, t1 = min(t0 + toks_per_wave, N);
+    // the token's position (x, y, view, batch) once per wave, then by increments (four 64-bit divisions per token before)
+    int x = 0, y = 0, v = 0, b = 0;
+    if (t0 < t1) { x = (int)(t0 % w); y = (int)((t0 / w) % h); v = (int)((t0 / ((long long)w * h)) % V); b = (int)(t0 / ((long long)w * h * V)); }
     for (long long t = t0; t < t1; ++t) {
-        const int x = (int)(t % w), y = (int)((t / w) % h), v = (int)((t / ((long long)w * h)) % V), b = (int)(t / ((long long)w * h * V));
         const float* img = lr + (size_t)b * (A * h) * (A * w) + (size_t)((v / A) * h) * (A * w) + (v % A) * w;
         const float g = dX0[t * 64 + c];
 #pragma unroll
@@ -1176,6 +1178,7 @@ __global__ __launch_bounds__(256) void k_conv0_wgrad(const float* __restrict__ d
             const float pv = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[yy * (A * w) + xx] : 0.0f;
             dw[tap] += g * pv;
         }
+        if (++x == w) { x = 0; if (++y == h) { y = 0; if (++v == V) { v = 0; ++b; } } }
     }
 #pragma unroll
     for (int t = 0; t < 9; ++t) part[wv * 576 + c * 9 + t] = dw[t];
