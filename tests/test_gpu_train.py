@@ -399,7 +399,7 @@ def test_fit_trains_and_writes_reference_format_checkpoints(tmp_path):
         assert torch.equal(fresh(lr), net.eval()(lr))
 
 
-@pytest.mark.parametrize("hw", [(32, 32), (33, 35)], ids=["32x32", "33x35_ragged"])
+@pytest.mark.parametrize("hw", [(32, 32), (33, 35), (26, 32)], ids=["32x32", "33x35_ragged", "26x32_rows_across_workgroups"])
 @pytest.mark.parametrize("math", MATHS)
 def test_full_size_backward_properties_cfg3(math, hw):
     """BASELINE configs[2] shape (A5, 2x, 32x32 LR views), where autograd over the CPU oracle takes minutes: properties
@@ -408,9 +408,12 @@ def test_full_size_backward_properties_cfg3(math, hw):
     per-patch gradients; and the forward-with-tape must agree with the fused inference kernels.  Three patches are 76 800 tokens:
     the batch runs the ring-fed GEMM kernel (k_linr, above 65 536 tokens), the single patches the direct one (k_lin) -- (ii) and
     the forward comparison hold the two against each other and against the inference path.  33 x 35 views: 86 625 tokens, not
-    a multiple of 32 -- partial tiles, waves past the end that only serve the ring, 32-token tiles that straddle image rows."""
-    A, s, B = 5, 2, 3
+    a multiple of 32 -- partial tiles, waves past the end that only serve the ring, 32-token tiles that straddle image rows.
+    26 x 32 views: the one-image-row-per-wave 3x3 paths (lane shifts in the GEMM, ten values per lane in the weight gradient) with
+    workgroups that straddle two images (832 tokens per image = 6.5 workgroups)."""
+    A, s = 5, 2
     h, w = hw
+    B = 3 if h * w >= 1024 else 4                                        # > 65 536 tokens: the batch runs k_linr
     tol = {"fp32": 2e-5, "bf16x3": 1e-4}[math]
     sd_np = deterministic_state(64, s, seed=1, flavor="stress")
     names = [n for n, _, _ in param_table(64, s)]
