@@ -730,7 +730,7 @@ int lft_debug_conv64(const void* packed, int which, int with_res, const void* in
     return 0;
 }
 
-#ifdef LFT_EXPERIMENT
+#if defined(LFT_EXPERIMENT) && !defined(LFT_ISA_MARKS)
 // Diagnostic build only (lft_experiment.cuh): copy the stamp buffer to the host (synchronises).
 int lft_debug_read_stamps(unsigned long long* host_out, int n) {
     LFT_HIP_OK(hipDeviceSynchronize());
@@ -814,7 +814,9 @@ int lft_train_tape_bytes(int B, int A, int h, int w, int s, size_t* out_bytes) {
     Dims d; int rc;
     if (!out_bytes) return fail(LFT_ERR_ARG, "out_bytes is null");
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
-    *out_bytes = train_layout(d).total * sizeof(float);
+    const TrainLayout T = train_layout(d);
+    if (T.rc) return T.rc;                                      // the sizing run of the backward pass failed: no tape size to report
+    *out_bytes = T.total * sizeof(float);
     return 0;
 }
 int lft_train_grad_floats(int s, size_t* out_floats) {
@@ -828,6 +830,7 @@ int lft_train_tape_offset(const char* name, int B, int A, int h, int w, int s, s
     if (!name || !out_float_offset) return fail(LFT_ERR_ARG, "null pointer");
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
     const TrainLayout T = train_layout(d);
+    if (T.rc) return T.rc;
     const std::string n(name);
     auto layer = [&](char c) { return c - '0'; };
     if (n == "x0") *out_float_offset = T.x0; else if (n == "feat") *out_float_offset = T.feat;

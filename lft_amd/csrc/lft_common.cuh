@@ -67,6 +67,7 @@ typedef unsigned int raw16 __attribute__((ext_vector_type(4), may_alias));
 #include "lft_experiment.cuh"
 #else
 #define LFT_STAMP(slot) ((void)0)
+#define LFT_STAMP_IT(slot, it_ofs) ((void)0)
 #endif
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one private 4 MiB L2): consecutive block

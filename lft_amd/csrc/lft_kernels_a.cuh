@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
 
         f32x16 x[2], n[2];
         load_tile<2, T>(X + off0, V, lane, x, scr, vstride);                              // rows = views: 8 lanes x 16 B per row
-        LFT_STAMP(2 + 5 * stamp_it);
+        LFT_STAMP_IT(2, 5 * stamp_it);
         {
             typename RawPiece<float>::type pr[8];
             load_lane_major_raw<2, float>(pe, lane, pr);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) mma(xf[ks], frag_from_pieces(smem + (16 + nt * 4 + ks) * FB, lane, T()), v[nt]);
 
-        LFT_STAMP(3 + 5 * stamp_it);
+        LFT_STAMP_IT(3, 5 * stamp_it);
 #pragma unroll
         for (int hd = 0; hd < 8; ++hd) {
             const int nt = hd >> 2, s = (hd >> 1) & 1, half = hd & 1;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
             for (int i = 0; i < 4; ++i) o[nt][4 * (hd & 3) + i] = oh[4 * (hd & 3) + i] * inv;
         }
 
-        LFT_STAMP(4 + 5 * stamp_it);
+        LFT_STAMP_IT(4, 5 * stamp_it);
         Frag<T> of[4];
         acc_frags<2, T>(o, of);
         linear_lds<2, 4, T>(smem, 24, lane, of, x);              // t = x + O Wo^T
@@ -436,9 +436,9 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
         Frag<T> hf[8];
         acc_frags_relu<4>(hid, hf);
         linear_lds<2, 8, T>(smem, 48, lane, hf, x);
-        LFT_STAMP(5 + 5 * stamp_it);
+        LFT_STAMP_IT(5, 5 * stamp_it);
         store_tile<2, T>(Y + off0, V, lane, x, scr, vstride);
-        LFT_STAMP(6 + 5 * stamp_it);
+        LFT_STAMP_IT(6, 5 * stamp_it);
         stamp_it = 1;
     }
     publish_status(status, bad);

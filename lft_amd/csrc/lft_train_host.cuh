@@ -111,6 +111,7 @@ struct TrainLayout {
     // backward scratch
     size_t bwd, bwd_floats, gu, stats, part, pgb;       // bwd: arena of the backward pass's gradient tensors (re-used as they die)
     size_t part_floats, total;                   // total in floats
+    int rc = 0;                                  // status of the sizing (dry) run of the backward pass: non-zero = the layout is not usable
 };
 constexpr int kWgChunksMax = 512;                // ... raised up to this for small matrices (wgrad)
 constexpr int kWgChunks = 128;                   // token chunks (= workgroups of 4 waves) of a weight-gradient launch
@@ -118,7 +119,7 @@ constexpr int kLnBlocks = 512;                   // workgroups (= partial rows) 
 constexpr int kTailWaves = 2048;                 // waves of the up-sampler / conv0 weight-gradient kernels
 inline int wg_chunks(long long N) { return (int)std::min<long long>(kWgChunks, std::max<long long>(4, N / 512)); }   // workgroups of 4 waves, >= 128 tokens per wave
 
-struct BwdSizes { size_t arena, part; };           // floats: peak live set of the gradient arena, high-water mark of the partial sums
+struct BwdSizes { size_t arena, part; int rc; };   // floats: peak live set of the gradient arena, high-water mark of the partial sums; rc of the dry run
 BwdSizes bwd_sizes(const Dims& d);
 TrainLayout train_layout(const Dims& d) {
     TrainLayout T;
@@ -146,6 +147,7 @@ TrainLayout train_layout(const Dims& d) {
     // anything (bwd_sizes).  Round 2 gave every tensor a buffer of its own (40 KB per token) so that the weight-gradient
     // kernels could run on a second stream: that overlap bought 3 % and cost half of the tape.
     const BwdSizes bsz = bwd_sizes(d);
+    T.rc = bsz.rc;                               // callers refuse a layout whose sizing run failed (the message is in lft_last_error)
     T.bwd_floats = bsz.arena;
     T.bwd = take(T.bwd_floats);
     T.gu = take(n * 64 * ss);
@@ -195,7 +197,12 @@ struct TrainCtx {
     size_t* part_peak = nullptr;   // its high-water mark (the dry run sizes the buffer with it)
     const float* gbase = nullptr;  // flat gradient buffer (segment destinations are offsets into it)
     bool dry = false;              // sizing pass: allocation sequence only, nothing is launched
+    const bool* arena_overflow = nullptr;   // backward only: set by BwdArena::get when a request does not fit -- no kernel is launched after that
     float* F(size_t off) const { return tp + off; }
+    int launch_ok() const {        // every launcher of the backward pass asks before it enqueues anything
+        if (arena_overflow && *arena_overflow) return fail(LFT_ERR_ARG, "internal: backward arena overflow (a request did not fit the sized arena); nothing launched for it");
+        return 0;
+    }
 };
 
 // n floats of the partial-sum buffer (released as a whole by the next k_reduce_all)
@@ -210,6 +217,7 @@ int part_take(const TrainCtx& c, size_t n, size_t* off) {
 int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int ldx, int flip, int act, const float* R, int ldr,
             float* Y, int ldy, long long N, const float* M = nullptr, int mact = 0) {
     if (c.dry) return 0;
+    if (int ok_ = c.launch_ok()) return ok_;
     const WView& v = c.W.v[view];
     if (nOT <= 0) nOT = v.OT;
     if ((v.taps != 1 && (ot0 || nOT != v.OT))) return fail(LFT_ERR_ARG, "run_lin: bad tile block (view %d)", view);
@@ -225,7 +233,10 @@ int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int l
     // four tiles, or the view's last group of two; large N only (below, the coalesced-input form of k_lin is the faster one)
     const bool full4 = nt == 4 && ot0 % 4 == 0 && ot0 + nOT <= (v.OT / 4) * 4;
     const bool last2 = nt == 2 && nOT == 2 && v.OT % 4 == 2 && ot0 == (v.OT / 4) * 4;
-    const bool ring = N > 65536 && (full4 || last2) && (v.taps == 1 || nOT == v.OT);
+    // k_linr's own preconditions, enforced here (a view that misses them takes k_lin): for 3x3 views its chunk stream is
+    // addressed as tap * OT * KS + c * NT, i.e. the workgroup's NT tiles must be ALL of the view's output tiles (OT == nt); the
+    // generic loop consumes two k-steps per iteration, so the stream length taps * KS must be even
+    const bool ring = N > 65536 && (full4 || last2) && (v.taps == 1 || (nOT == v.OT && v.OT == nt)) && (v.taps * v.KS) % 2 == 0;
     const bool tiled = v.taps == 1 && v.KS % 4 == 0 && N <= 65536;       // measured: +7 % at 25.6 k tokens, -4 % at 205 k
 #define LFT_LAUNCH_LIN(NTV)                                                                                          \
     do {                                                                                                             \
@@ -283,6 +294,7 @@ int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, in
     int rc;
     if ((rc = part_take(c, (size_t)nch * wsize, &poff))) return rc;
     if (c.dry) return 0;
+    if (int ok_ = c.launch_ok()) return ok_;
     hipStream_t ws = c.st;
     WgP p{dY, Co, X, Ci, c.F(c.T.part) + poff, wsize, Ci * taps, taps, 1, Co, Ci, taps, c.d.h, c.d.w, N, len, 1, nch, 1};
     const bool m3 = c.math == LFT_MATH_BF16X3;
@@ -335,6 +347,7 @@ int ln_bwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, 
     int rc;
     if ((rc = part_take(c, (size_t)nb * 2 * C, &poff))) return rc;
     if (c.dry) return 0;
+    if (int ok_ = c.launch_ok()) return ok_;
     float* pgb = c.F(c.T.part) + poff;
     if (C == 64) k_ln_bwd<64><<<nb, 256, 0, c.st>>>(X, pe, mode, g, dY, add, out, pgb, N, c.d.hw, c.d.V);
     else k_ln_bwd<128><<<nb, 256, 0, c.st>>>(X, pe, mode, g, dY, add, out, pgb, N, c.d.hw, c.d.V);
@@ -345,12 +358,14 @@ int ln_bwd(const TrainCtx& c, int C, const float* X, const float* pe, int mode, 
 }
 int act_bwd(const TrainCtx& c, const float* g, const float* y, float* out, long long n, int mode) {
     if (c.dry) return 0;
+    if (int ok_ = c.launch_ok()) return ok_;
     k_act_bwd<<<blocks_for(n / 4, 256), 256, 0, c.st>>>(g, y, out, n / 4, mode);
     LFT_LAUNCH_OK("k_act_bwd");
     return 0;
 }
 int add3(const TrainCtx& c, float* out, const float* a, const float* b, long long n) {
     if (c.dry) return 0;
+    if (int ok_ = c.launch_ok()) return ok_;
     k_add3<<<blocks_for(n / 4, 256), 256, 0, c.st>>>(out, a, b, n / 4);
     LFT_LAUNCH_OK("k_add3");
     return 0;
@@ -363,6 +378,7 @@ int add_to(const TrainCtx& c, float* a, const float* b, long long n) {
 template <bool BWD>
 int ang_attn(const TrainCtx& c, const float* QK, const float* Vv, float* O, const float* dO, float* dQK, float* dV) {
     if (c.dry) return 0;
+    if (int ok_ = c.launch_ok()) return ok_;
     const int V = c.d.V, npix = c.d.B * c.d.hw;
     int rc;
     if (V <= 32) {
@@ -380,6 +396,7 @@ int ang_attn(const TrainCtx& c, const float* QK, const float* Vv, float* O, cons
 template <int MODE>
 int win_attn(const TrainCtx& c, const float* Q, const float* K, const float* V, float* O, const float* dO, float* dQ, float* dK, float* dV) {   // Q | K and dQ | dK: [N][256]
     if (c.dry) return 0;
+    if (int ok_ = c.launch_ok()) return ok_;
     const Dims& d = c.d;
     const unsigned tiles = (unsigned)(((d.w + kWaTX - 1) / kWaTX) * ((d.h + kWaTY - 1) / kWaTY) * d.B * d.V);
     int rc;
@@ -392,6 +409,7 @@ int win_attn(const TrainCtx& c, const float* Q, const float* K, const float* V, 
 // ---------------------------------------------------------------------------- forward with tape
 int train_forward(const float* const* P, const float* lr, float* out, float* tape, const Dims& d, int math, hipStream_t st) {
     const TrainLayout T = train_layout(d);
+    if (T.rc) return T.rc;
     std::vector<PackOp> ops;
     const WViews WV = build_views(P, d.s, &ops);
     const TrainCtx c{d, tape, T, WV, st, math};
@@ -469,6 +487,8 @@ typedef int (*BucketFn)(void* user, int bucket, size_t first_float, size_t n_flo
 struct BwdArena {
     float* base = nullptr;
     size_t cap = 0, peak = 0;
+    bool overflow = false;                           // a request went past `cap`: the pointer handed out is the arena's base (valid
+                                                     // memory) and TrainCtx::launch_ok() stops every launcher before it enqueues
     std::vector<std::pair<size_t, size_t>> used;     // (offset, floats), sorted by offset
     float* get(size_t n) {
         n = (n + 63) & ~(size_t)63;
@@ -479,6 +499,7 @@ struct BwdArena {
         }
         used.insert(used.begin() + (long)i, std::make_pair(off, n));
         peak = std::max(peak, off + n);
+        if (off + n > cap) { overflow = true; return base; }
         return base + off;
     }
     void put(const float* p) {
@@ -494,6 +515,7 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
                    bool dry = false, size_t* peak_out = nullptr, size_t* part_peak_out = nullptr) {
     TrainLayout Tdry{};
     const TrainLayout T = dry ? Tdry : train_layout(d);
+    if (T.rc) return T.rc;
     const WViews WV = build_views(nullptr, d.s, nullptr);            // packed by this step's lft_train_forward
     RedTab red{};                                                    // every partial-sum producer registers a segment here
     size_t part_used = 0, part_peak = 0;
@@ -508,6 +530,7 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
     BwdArena A;
     A.base = c.F(T.bwd);
     A.cap = dry ? (size_t)-1 : T.bwd_floats;
+    c.arena_overflow = &A.overflow;
     auto nb = [&](int width) { return A.get((size_t)N * width); };   // [N][width] gradient buffer; A.put() at its last use
     // End of a gradient bucket: the partial sums registered since the last bucket are reduced (one table-driven launch) and
     // their region is free again, then the caller is told -- everything enqueued before the callback belongs to the bucket,
@@ -698,7 +721,8 @@ BwdSizes bwd_sizes(const Dims& d) {
     static thread_local BwdSizes last_sz{};
     if (last_sz.arena && last.B == d.B && last.A == d.A && last.h == d.h && last.w == d.w && last.s == d.s) return last_sz;
     BwdSizes sz{};
-    (void)train_backward(nullptr, nullptr, nullptr, nullptr, nullptr, d, LFT_MATH_F32, nullptr, nullptr, nullptr, nullptr, true, &sz.arena, &sz.part);
+    sz.rc = train_backward(nullptr, nullptr, nullptr, nullptr, nullptr, d, LFT_MATH_F32, nullptr, nullptr, nullptr, nullptr, true, &sz.arena, &sz.part);
+    if (sz.rc) { sz.arena = sz.part = 0; return sz; }             // not cached: the next call reports the failure again
     last = d; last_sz = sz;
     return sz;
 }

@@ -108,6 +108,12 @@ class get_model(nn.Module):
         key = (str(dev), B, h, w, prec)
         cur = self._work.get(slot)
         if cur is None or cur[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                # A workspace created inside a capture would put its status reset into the graph: every replay would then
+                # clear the sticky word, and an overflow in replay n would be erased by replay n+1 (one read must cover every
+                # replay since the last reset, include/lft_hip.h).  Allocation during capture is not wanted either.
+                raise _lib.LftError("a workspace would have to be created while a HIP graph is being captured: run one eager "
+                                    "forward of this shape (same _slot_base) first (GraphedForward needs warmup >= 1)")
             nbytes = _lib.workspace_bytes(B, self.angRes, h, w, self.factor, prec)
             cur = (key, torch.empty(nbytes, dtype=torch.uint8, device=dev))
             self._work[slot] = cur
@@ -196,6 +202,9 @@ class GraphedForward:
     (re-create after load_state_dict / optimizer steps).  Usage: g = GraphedForward(net, example_lr); out = g(lr)."""
 
     def __init__(self, net: "get_model", example: torch.Tensor, warmup: int = 3, slot_base: int = 0):
+        if warmup < 1:
+            raise ValueError("GraphedForward needs at least one eager warm-up forward: it creates the workspaces and clears their "
+                             "status words OUTSIDE the captured graph")
         self.net = net
         self.static_in = example.detach().clone().contiguous()
         with torch.no_grad():

@@ -45,6 +45,9 @@ def split_operands(line):
     return regs(ops[0]), regs(",".join(ops[1:]))
 
 
+ASM_LOADS = {}          # kernel symbol -> inline-asm global loads seen (a parsing change must not make the check pass vacuously)
+
+
 def check(path, filters):
     kernel, in_asm, queue, bad = None, False, [], []        # queue: (is_asm_load, destination registers, line number)
     for ln, line in enumerate(open(path), 1):
@@ -64,7 +67,10 @@ def check(path, filters):
         m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", text)
         if m:
             n = int(m.group(1))
-            queue = queue[len(queue) - n:] if n else []
+            if n == 0:
+                queue = []
+            elif n < len(queue):                 # n >= len(queue): nothing retires (a negative slice start would DROP pending loads)
+                queue = queue[len(queue) - n:]
             continue
         if "s_endpgm" in text:
             kernel, queue = None, []
@@ -77,7 +83,13 @@ def check(path, filters):
         if VM.match(text):
             is_load = "load" in text and "lds" not in text
             queue.append((in_asm and is_load, dst if is_load else set(), ln))
+            if in_asm and is_load:
+                ASM_LOADS[kernel] = ASM_LOADS.get(kernel, 0) + 1
     return bad
+
+
+# kernels that are KNOWN to use inline-asm loads under counted waits (mangled-name fragments): the check must have seen them
+EXPECT_ASM_LOADS = ("7k_spa_b",)            # (k_linr's rows became ordinary loads in round 3)
 
 
 def main():
@@ -97,7 +109,13 @@ def main():
     for kernel, ln, hit, text in bad:
         print(f"{kernel}:{ln}: v{hit} read before its asm load is waited for: {text}")
     print(f"{len(bad)} suspicious read(s)")
-    return 1 if bad else 0
+    print(f"inline-asm loads modelled: {sum(ASM_LOADS.values())} in {len(ASM_LOADS)} kernels")
+    vacuous = []
+    if args and args[0] == "--build" and not args[1:]:
+        vacuous = [k for k in EXPECT_ASM_LOADS if not any(k in name for name in ASM_LOADS)]
+        for k in vacuous:
+            print(f"NO inline-asm load was matched in any kernel named *{k}*: the listing format or the kernels changed -- the check is vacuous")
+    return 1 if bad or vacuous else 0
 
 
 if __name__ == "__main__":
