@@ -719,6 +719,21 @@ def main():
                 result["value_within_tolerance"] = (result["value"] if result["meets_tolerance"]
                                                     else result["parity_path"]["value"] if ok16 else result["parity_path"]["exact_fp32"]["value"])
                 result["value_within_tolerance_path"] = (args.precision if result["meets_tolerance"] else "fp16" if ok16 else "fp32")
+            if extras and args.config == "cfg2":
+                # north_star's second parity form, "PSNR within 0.01 dB": a small 5x5 2x model trained here by the repo's own trainer,
+                # held-out synthetic scenes through lft_amd.evaluate in each precision and through the CPU oracle (the checker);
+                # per view |PSNR(path, HR) - PSNR(oracle, HR)| (tests/psnr_util.py; tests/test_gpu_psnr.py gates the same figure)
+                note("PSNR-delta check against the CPU oracle on trained weights ...")
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import psnr_util as PU
+                pd = {}
+                for fam, fmax in (("hard_scenes", 0.25), ("smooth_scenes", 0.06)):
+                    sd_t, hist = PU.train_small_model(dev, fmax=fmax)
+                    r = PU.psnr_delta(dev, sd_t, PU.held_out_scenes(n=1, fmax=fmax))
+                    pd[fam] = {"train_loss_first_last": [hist[0], hist[-1]], **{p: {k: round(v, 5) if isinstance(v, float) else v for k, v in d.items()} for p, d in r.items()}}
+                result["psnr_delta_db"] = dict(pd, tolerance_db=0.01,
+                                               note="max over views of |PSNR(path, HR) - PSNR(oracle, HR)|; A5 2x model trained in this run (20 epochs, synthetic light fields), "
+                                                    "one held-out 5x5x48x48 scene per family through LFdivide / network / LFintegrate")
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -310,9 +310,10 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
         {   // spatial part 2: out_proj, FFN in 4 chunks, 1x1x1 conv.  out_proj's operand: bf16 -- the attention accumulators
             // inside k_spa_b (acc order); fp32 -- the attention output read back from memory by k_spa2 (natural k)
             std::vector<PackOp> ops;
-            // bf16 with lane-major Q / K / V (tok_lane_major): V's channels sit in LDS in acc order, which the acc-order read-out of
-            // the attention accumulators turns back into natural order -- natural packing again
-            ops.push_back(lin_op(q[4], 0, 128, 128, 0, 8, (sizeof(T) == 2 && !tok_lane_major<T>(d)) ? 1 : 0, 1.0f));
+            // 16-bit (k_spa_b): element (h, j) of the attention fragment is the head's channel label 8 h + j of the V tile in LDS.
+            // Row-major K / V: labels are the channels themselves -- natural packing.  Lane-major Q / K / V (tok_lane_major): k_spa1
+            // wrote each head's 16 channels in acc order, so label 8 h + j is channel acc(h, j) -- acc-order packing.
+            ops.push_back(lin_op(q[4], 0, 128, 128, 0, 8, (sizeof(T) == 2 && tok_lane_major<T>(d)) ? 1 : 0, 1.0f));
             for (int c = 0; c < 4; ++c) {
                 ops.push_back(lin_op(q[7], 64 * c, 64, 128, 0, 8, 1, 1.0f));
                 ops.push_back(lin_op(q[8], 0, 128, 256, 64 * c, 4, 1, 1.0f));

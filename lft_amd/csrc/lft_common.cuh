@@ -222,6 +222,15 @@ LFT_DEV void wg_barrier_keep_vm_lds_visible() {
     asm volatile("s_barrier" ::: "memory");
 }
 
+// Protocol notes for tools/lds_dma_hazards.py (the static check of every LDS-DMA pipeline): comment-only asm statements -- no
+// instruction is emitted; they only name, in the assembly listing, the LDS slot the following DMA pieces fill (DMA), the point from
+// which a slot is read (USE) and the point at which its reads have been issued for the last time (DONE).  A note is written only
+// where the slot is a compile-time constant after inlining and unrolling (the straight-line kernels); in run-time loops (k_up,
+// k_ang, k_linr) the slot is a register value and the tool reports the ring as not modelled there.
+#define LFT_NOTE_ASM_(kind, ring, slot) asm volatile("; LFT_NOTE " kind " ring=%0 slot=%1" :: "i"(ring), "i"(slot))
+#define LFT_DMA_NOTE(kind, ring, slot) do { if (__builtin_constant_p(slot)) LFT_NOTE_ASM_(kind, ring, slot); } while (0)
+constexpr int kNoteWRing = 0, kNoteWRingPipe = 1, kNoteKV = 2, kNoteConvIn = 3, kNoteAngW = 4;
+
 // Weight ring: the 4 waves of a workgroup consume the same fragment stream in lock-step.  The stream is cut
 // into chunks of CH fragments held in a 3-slot LDS ring: while chunk c feeds the MFMAs, chunks c+1 and c+2 are
 // in flight / landed (LDS-DMA issued two chunks ahead: one chunk of MFMAs, ~0.25 us, is shorter than the
@@ -259,6 +268,7 @@ struct WRing {
         const char* src = g + (size_t)c * CHUNK_BYTES;
         char* dst = lds + (c % NBUF) * CHUNK_BYTES;
         const int last = (nfrag - c * CH) * FragInfo<T>::PIECES - 1;    // last piece that exists in this chunk
+        LFT_DMA_NOTE("DMA", kNoteWRing, c % NBUF);
 #pragma unroll
         for (int i = 0; i < PIECES_PER_WAVE; ++i) {
             const int piece = min(wave * PIECES_PER_WAVE + i, last);
@@ -274,9 +284,11 @@ struct WRing {
     LFT_MEM Frag<T> next() {
         const int c = pos / CH, i = pos % CH;
         if (i == 0) {
+            if (c > 0) LFT_DMA_NOTE("DONE", kNoteWRing, (c + NBUF - 1) % NBUF);   // chunk c-1 has been read for the last time
             wait_landed((c + 1) * CH < nfrag);
             wg_barrier_keep_vm();
             issue(c + 2);
+            LFT_DMA_NOTE("USE", kNoteWRing, c % NBUF);
         }
         ++pos;
         return frag_from_pieces(lds + (c % NBUF) * CHUNK_BYTES + i * FRAG_BYTES, lane, T());
@@ -324,6 +336,7 @@ struct WRingPipe {
         const char* src = g + (size_t)c * CHUNK_BYTES;
         char* dst = slot(c);
         const int last = (NFRAG - c * CH) * FragInfo<T>::PIECES - 1;
+        LFT_DMA_NOTE("DMA", kNoteWRingPipe, c % NBUF);
 #pragma unroll
         for (int i = 0; i < PIECES_PER_WAVE; ++i) {
             const int piece = min(wave * PIECES_PER_WAVE + i, last);
@@ -332,12 +345,14 @@ struct WRingPipe {
     }
     template <int C> LFT_MEM void fetch() {                             // LDS -> register set C & 1; the reads are in flight on return
         const char* base = slot(C);
+        LFT_NOTE_ASM_("USE", kNoteWRingPipe, C % NBUF);
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if (C * CH + i < NFRAG) {
                 if constexpr (C & 1) fr1[i] = frag_from_pieces(base + i * FRAG_BYTES, lane, T());
                 else fr0[i] = frag_from_pieces(base + i * FRAG_BYTES, lane, T());
             }
+        LFT_NOTE_ASM_("DONE", kNoteWRingPipe, C % NBUF);                  // the chunk now lives in registers: its slot is free after the next barrier
     }
     LFT_MEM void init(const T* stream, char* lds_base) {                // all slots free from the start
         setup(stream, lds_base);
@@ -650,13 +665,16 @@ LFT_DEV void load_tile(const T* __restrict__ gbase, int nvalid, int lane, f32x16
 }
 
 // Tile I/O for a wave whose 32 tokens are NOT consecutive in memory: an 8 x 4 block of one view image (the windowed
-// attention's query block).  Row r of the tile = token (y0 + r / 8, x0 + r % 8): 8 consecutive tokens per image row.
+// attention's query block), taken as two 4 x 4 blocks side by side.  Row r of the tile = token 16 b + 4 py + px of k_spa_b:
+// image row y0 + ((r >> 2) & 3), column x0 + 4 (r >> 4) + (r & 3).
 struct BlkRows {
     int img_row_bytes;     // bytes from one image row to the next (w * bytes per token row)
     int tok_bytes;         // bytes per token row
     int nrow, ncol;        // rows (<= 4) and columns (<= 8) of the block that lie inside the image
-    LFT_MEM size_t off(int row) const { return (size_t)(row >> 3) * img_row_bytes + (size_t)(row & 7) * tok_bytes; }
-    LFT_MEM bool ok(int row) const { return (row >> 3) < nrow && (row & 7) < ncol; }
+    LFT_MEM static int py(int row) { return (row >> 2) & 3; }
+    LFT_MEM static int px(int row) { return 4 * (row >> 4) + (row & 3); }
+    LFT_MEM size_t off(int row) const { return (size_t)py(row) * img_row_bytes + (size_t)px(row) * tok_bytes; }
+    LFT_MEM bool ok(int row) const { return py(row) < nrow && px(row) < ncol; }
 };
 // As load_tile / store_tile, with the row -> address map given by `rm` (offsets relative to gbase, which must be a
 // readable address even when no row is valid).
@@ -825,6 +843,51 @@ LFT_DEV float xhalf_max(float v) { float lo, hi; xhalf_split(v, lo, hi); return 
 LFT_DEV float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 LFT_DEV float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
 #endif
+
+// ------------------------------------------------------------------------------------------
+// 16-column MFMA forms (v_mfma_f32_16x16x16_{bf16,f16}, v_mfma_f32_16x16x32_{bf16,f16}) for the windowed attention's score
+// tiles: a 4 x 4 query block sees an 8 x 8 key neighbourhood (64 keys), a 32-query block 96 -- a third fewer scores to
+// exponentiate per query.  Lane maps (checked on the card by tools/micro/mfma_small.hip): lane l = 16 g + i holds
+//   A[row i][k = K4 g + j],  B[k = K4 g + j][col i],  C / D[row 4 g + e][col i]        (K4 = 4 for x16, 8 for x32; e = 0..3)
+// so a result tile (row on the register, column on the lane) is, converted, directly the B operand of a product that sums over
+// its rows -- the same idiom as the 32-wide tiles.
+// Two 16-column operands <-> one 32-column fragment: v_permlane16_swap_b32 D, S exchanges rows (16 lanes) 1, 3 of D with rows
+// 0, 2 of S.  For a 32x32x16 fragment (lane 32 h + r: token r, elements j = 0..7) with X = elements 0..3 and Y = elements 4..7,
+// swap(X, Y) leaves X = the 16x16x16 operand of tokens 0..15 (row g: k = 4 g .. 4 g + 3 <-> fragment labels 8 h + j in order) and
+// Y = that of tokens 16..31; the same swap turns two 16-column result tiles back into one 32-column fragment.
+// ------------------------------------------------------------------------------------------
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+LFT_DEV f32x4 mfma16k16(u32x2 a, u32x2 b, f32x4 c, bf16_t) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4v, a), __builtin_bit_cast(s16x4v, b), c, 0, 0, 0);
+}
+LFT_DEV f32x4 mfma16k16(u32x2 a, u32x2 b, f32x4 c, f16_t) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+}
+LFT_DEV f32x4 mfma16k32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+LFT_DEV f32x4 mfma16k32(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// s_nop 1: wait states between the VALU writes of the operands and the swap (as xhalf_split).  The operands are always VALU
+// results here (conversions, maxima, sums), never raw MFMA results (the hazard recogniser does not pad an asm statement).
+LFT_DEV void swap16(unsigned& d, unsigned& s) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(d), "+v"(s)); }
+LFT_DEV void swap16(float& d, float& s) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(d), "+v"(s)); }
+LFT_DEV void swap32(float& d, float& s) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(d), "+v"(s)); }
+// 32-column fragment (4 registers) -> the two 16-column operands in place: registers 0, 1 = tokens 0..15, registers 2, 3 = tokens 16..31
+LFT_DEV void frag_to_blocks(raw16& f) {
+    unsigned a0 = f[0], a1 = f[1], b0 = f[2], b1 = f[3];
+    swap16(a0, b0);
+    swap16(a1, b1);
+    f = raw16{a0, a1, b0, b1};
+}
+// a, b: a lane's partial results for query column (lane & 15) of blocks A and B; on return EVERY lane holds, for its column, the
+// combination over the four 16-lane rows -- a for block A, b for block B (3 swaps, 2 operations, 2 copies for both blocks).
+template <typename OP> LFT_DEV void xrow_combine2(float& a, float& b, OP op) {
+    swap16(a, b);                               // a = [A0 B0 A2 B2]   b = [A1 B1 A3 B3]   (by lane row)
+    float c = op(a, b), c2 = c;                 // [A01 B01 A23 B23]
+    swap32(c, c2);                              // c = [A01 B01 A01 B01]   c2 = [A23 B23 A23 B23]
+    float d = op(c, c2), d2 = d;                // [A B A B]
+    swap16(d, d2);                              // d = [A A A A]   d2 = [B B B B]
+    a = d; b = d2;
+}
 
 // LayerNorm over the NT*32 channels of each token (biased variance, eps inside the sqrt, affine),
 // as nn.LayerNorm does (reference LFT.py:127,136,199,208).  In place.  gamma/beta may point to LDS (kernels

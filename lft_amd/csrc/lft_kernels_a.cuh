@@ -204,6 +204,7 @@ LFT_DEV void stage_conv_input(const T* __restrict__ img, int p0, int hw, int w, 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int npieces = CI::dma_pieces(w);
+    LFT_NOTE_ASM_("DMA", kNoteConvIn, 0);
     for (int piece = wave; piece < npieces; piece += NW) {
         const int slot = piece * CI::SLOTS_PER_DMA + lane / CI::PPR, cpos = lane % CI::PPR;
         const int q = min(max(p0 - w - 1 + slot, 0), hw - 1);                       // clamped: out-of-image rows are masked at use
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv64(const T* __restrict__ in, T*
     clear_zero_row(zero_row);
     wait_staged();
     __syncthreads();                                                                 // ... and everybody else's
+    LFT_NOTE_ASM_("USE", kNoteConvIn, 0);
     f32x16 acc[2];
     zero_acc<2>(acc);
     conv3x3_tile<2, T, NW>(lds_in, zero_row, tl, p / w, p % w, ok, h, w, hh, ring, acc);
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
     unsigned bad = 0;                                                  // non-finite activation seen (layernorm_acc)
     {
         const char* g = reinterpret_cast<const char*>(ws);
+        LFT_NOTE_ASM_("DMA", kNoteAngW, 0);
 #pragma unroll
         for (int i = 0; i < 16 * FragInfo<T>::PIECES; ++i) {
             const int piece = wave * 16 * FragInfo<T>::PIECES + i;
@@ -348,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void k_ang(const T* __restrict__ X, T* __re
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own LDS-DMA pieces landed, then publish (see WRing::next)
     params_store(lds_ln, 256, lnv);
     __syncthreads();
+    LFT_NOTE_ASM_("USE", kNoteAngW, 0);
     LFT_STAMP(1);
     [[maybe_unused]] int stamp_it = 0;                                     // diagnostic build: second tile's stamps go to slots 7..11
     const bool ok = r < V;

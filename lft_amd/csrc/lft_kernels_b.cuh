@@ -67,6 +67,7 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
     LFT_STAMP(13);
     if (!PE_ONLY) params_store(lds_ln, 256, lnv);
     __syncthreads();                                                  // input tile, first weight chunks and LN parameters published
+    LFT_NOTE_ASM_("USE", kNoteConvIn, 0);
     LFT_STAMP(1);
     f32x16 t[4];
     zero_acc<4>(t);
@@ -143,6 +144,8 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa1(const T* __restri
 // 12 x 8 neighbourhood = 96 keys = three 32-key tiles; the workgroup's keys are the 8 x 36 halo tile around it.
 // ------------------------------------------------------------------------------------------
 constexpr int kAttTY = 4, kAttTX = 32, kAttHR = kAttTY + 4, kAttHC = kAttTX + 4;
+// quarter swizzle of the K / V halo tiles in LDS (k_spa_b): halo (row, column) -> XOR mask of the 16-byte quarter index
+LFT_DEV int att_swz(int row, int col) { return (row & 1) | (((col >> 2) & 1) << 1); }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(64 * NW, LFT_SPA_OCC) void k_spa2(const T* __restri
 // tokens then go through  t = tok + O Wo^T ; t += W2 relu(W1 LN'(t)) ; y = Wl t (+ global skip)  as in k_spa2.
 // Stream: Wo[4x8, ACC order] {W1c[2x8] W2c[4x4]} x4  Wl[2x8]  (176 fragments) through an 8-fragment-chunk ring, so that
 // ring + K/V halo tiles stay below 80 KiB and two workgroups share a CU.  TOK / skip / Y are row-major [token][channel];
-// a wave's 8 x 4 block is four runs of 8 consecutive tokens (BlkRows).
+// a wave's 8 x 4 block is two 4 x 4 blocks side by side (BlkRows: token 16 b + 4 py + px).
 // ------------------------------------------------------------------------------------------
 #ifndef LFT_SPAB_CHUNK
 #define LFT_SPAB_CHUNK 8
@@ -312,13 +315,17 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
     const int y0 = ty * kAttTY, x0 = tx * kAttTX, bxl = 8 * wave;          // block origin: (y0, x0 + bxl)
     const long long img0 = (long long)im * h * w;
     LFT_STAMP(16);
-    // this lane's query
-    const int qy = y0 + (r >> 3), qx = x0 + bxl + (r & 7);
+    // This lane's query.  The wave's 8 x 4 block is two 4 x 4 blocks side by side (columns bxl .. bxl+3 and bxl+4 .. bxl+7); token
+    // (= MFMA column) r = 16 b + 4 py + px: tokens 0..15 are block A, 16..31 block B, each row-major.  With that order the two
+    // 16-lane rows of a 32-column fragment's half ARE the two blocks, which is what lets v_permlane16_swap regroup a fragment
+    // into the score tiles' 16-column operands (frag_to_blocks).
+    const int qpx = 4 * (r >> 4) + (r & 3), qpy = (r >> 2) & 3;      // position inside the 8 x 4 block
+    const int qy = y0 + qpy, qx = x0 + bxl + qpx;
     const long long qtok = img0 + min(qy, h - 1) * w + min(qx, w - 1);
     // row-major Q: [token][128], head hd = channels 16 hd .. (natural order); lane-major: piece [k-step hd][32 hh + column] of
     // the tile of image row qy (acc order -- K / V come in the same order, so the dot products agree, and the channel order
     // of V^T's rows, i.e. of the attention output, is undone by packing Wo in natural k order: lft_api.hip)
-    const T* qptr = TOKLM ? Q + (img0 + (long long)min(qy, h - 1) * w + x0) * 128 + (32 * hh + bxl + (r & 7)) * 8
+    const T* qptr = TOKLM ? Q + (img0 + (long long)min(qy, h - 1) * w + x0) * 128 + (32 * hh + bxl + qpx) * 8
                                : Q + qtok * 128 + 8 * hh;
     constexpr int kQHead = TOKLM ? 512 : 16, kQPair = 2 * kQHead;     // element stride from one head / head pair to the next
     // K / V halo tiles (8 x 36 tokens x 2 heads = 64 B per token, unpadded) come in by LDS-DMA: no staging registers, no
@@ -331,11 +338,15 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
         // first slot, then row / column by carry (the kernel is bound by vector-instruction issue, prologue included)
         const int s0 = (wave & 1) * kAdPerWave * 16 + (lane >> 2), piece = lane & 3;
         int row = s0 / kAttHC, col = s0 % kAttHC;
-        const int pconst = TOKLM ? ((piece >> 1) * 512 + (piece & 1) * 256) * 2 : piece * 16;      // lane-major: piece = (head, half)
 #pragma unroll
         for (int i = 0; i < kAdPerWave; ++i) {
             const int gy = min(max(y0 - 2 + row, 0), h - 1), gx = min(max(x0 - 2 + col, 0), w - 1);
             const int tk = gy * w + gx;
+            // Bank swizzle: the four 16-byte quarters of a token's 64 bytes are stored XOR-permuted by (halo row parity, bit 2 of the
+            // halo column).  A score tile's K read (16 tokens = 2 rows x 8 columns, one quarter) and a V^T transposing read (8 tokens of
+            // one row, two quarters) then touch all 64 banks once per 32-lane half; unswizzled (64-byte token stride) both are 4-way.
+            const int pq = piece ^ att_swz(row, col);
+            const int pconst = TOKLM ? ((pq >> 1) * 512 + (pq & 1) * 256) * 2 : pq * 16;               // lane-major: piece = (head, half)
             dofs[i] = (TOKLM ? ((tk & ~31) << 8) + ((tk & 31) << 4) : tk * 256) + pconst;
             col += 16;
             if (col >= kAttHC) { col -= kAttHC; row += 1; }
@@ -347,6 +358,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
     const char* const dsrc = reinterpret_cast<const char*>((wave < 2 ? K : Vv) + img0 * 128);
     const int ddst = (wave < 2 ? 0 : kAdTile) + (wave & 1) * kAdPerWave * 1024;       // this wave's part of a buffer
     auto stage = [&](int hg, char* buf) {
+        LFT_DMA_NOTE("DMA", kNoteKV, hg & 1);
 #pragma unroll
         for (int i = 0; i < kAdPerWave; ++i) glds16_asm(dsrc + dofs[i] + hg * kDmaPair, buf + ddst + i * 1024);
     };
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
         // two sets of eight fragment registers, 16 KB from L2 per wave and set.
         raw16 lnv1, per[8], wqa[8], wqb[8];
         const int ty_ = min(qy, h - 1);
-        const int lane_piece = (32 * hh + bxl + (r & 7)) * 8;            // this lane's 16-byte piece inside a k-step of a lane-major tile
+        const int lane_piece = (32 * hh + bxl + qpx) * 8;                // this lane's 16-byte piece inside a k-step of a lane-major tile
         const char* tsrc = reinterpret_cast<const char*>(TOK + (img0 + (long long)ty_ * w + x0) * 128 + lane_piece);
         const char* psrc = reinterpret_cast<const char*>(petok + ((long long)ty_ * w + x0) * 128 + lane_piece);
         const char* wsrc = reinterpret_cast<const char*>(wq) + lane * 16;
@@ -410,6 +422,13 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
         q_head_pair<T>(wqa, nf, qfr[4], qfr[5]);
         wait_vm_8<0>(wqb);
         q_head_pair<T>(wqb, nf, qfr[6], qfr[7]);
+        // each head's query fragment -> the two blocks' 16-column operands, in place (2 swaps per head)
+#pragma unroll
+        for (int hd = 0; hd < 8; ++hd) {
+            raw16 f = __builtin_bit_cast(raw16, qfr[hd].v);
+            frag_to_blocks(f);
+            qfr[hd].v = __builtin_bit_cast(V8, f);
+        }
     } else {
         lnv = params_load(ln + 256, 256);
         stage(0, bufA);
@@ -422,54 +441,49 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
     rows.nrow = max(0, min(4, h - y0)); rows.ncol = max(0, min(8, w - (x0 + bxl)));
     if (rows.ncol == 0) rows.nrow = 0;
     const long long tok0 = img0 + (long long)min(y0, h - 1) * w + min(x0 + bxl, w - 1);
-    // 0 / -inf bias of the three score tiles: key kk = 32 j + row -> (jy, jx) = (kk / 12, kk % 12) of the 12 x 8 neighbourhood
-    f32x16 bias[3];
+    // Score tiles: per block b (columns bxl + 4 b ..) the 8 x 8 key neighbourhood = halo rows 0..7, halo columns bxl + 4 b .. + 7,
+    // cut into four 16-key tiles (tile t = halo rows 2 t, 2 t + 1, key kk -> row kk / 8, column kk % 8).  S^T[key, query] of tile
+    // (b, t): lane 16 g + qi holds query qi of block b against keys 4 g .. 4 g + 3 (register e), i.e. halo row 2 t + (g >> 1),
+    // neighbourhood columns 4 (g & 1) + e.  The 0 / -inf bias (window, image border, the `min(h, x+3)` quirk of LFT.py:155) is the
+    // product of a row mask and a column mask of the lane's query: one bit-field extract + AND per element.
+    const int g4 = lane >> 4, qi = lane & 15;
+    f32x4 bias[2][4];
     {
-        // Validity of the 96 neighbourhood positions for this lane's query as a bit mask, built from a row mask and a column
-        // mask (the window is a rectangle), then one bit-field extract + AND per bias element: ~140 vector instructions
-        // instead of ~400 for 48 four-sided comparisons.
-        const int wy0 = max(0, qy - 2), wy1 = min(h, qy + 3), wx0 = max(0, qx - 2), wx1 = min(min(h, qx + 3), w);   // reference LFT.py:155 (sic)
-        const int cy0 = y0 - 2, cx0 = x0 + bxl - 2;                        // image position of neighbourhood element (0, 0)
+        const int wy0 = max(0, qy - 2), wy1 = min(h, qy + 3), cy0 = y0 - 2;
         const int ya = min(max(wy0 - cy0, 0), 8), yb = min(max(wy1 - cy0, 0), 8);
-        const int xa = min(max(wx0 - cx0, 0), 12), xb = min(max(wx1 - cx0, 0), 12);
-        const unsigned ymask = ((1u << yb) - 1u) & ~((1u << ya) - 1u);     // empty when yb <= ya
-        const unsigned xmask = ((1u << xb) - 1u) & ~((1u << xa) - 1u);
-        unsigned d0 = 0, d1 = 0, d2 = 0;                                   // bit 12 row + col of (d2:d1:d0) = element (row, col) is in the window
+        const unsigned ymask = ((1u << yb) - 1u) & ~((1u << ya) - 1u);     // halo rows inside the window (empty when yb <= ya)
+        const int gy = g4 >> 1, gx4 = 4 * (g4 & 1);
 #pragma unroll
-        for (int row = 0; row < 8; ++row) {
-            const unsigned t = (unsigned)__builtin_amdgcn_sbfe((int)ymask, row, 1) & xmask;
-            const int bit = 12 * row;
-            if (bit < 32) d0 |= t << bit;
-            if (bit < 32 && bit + 12 > 32) d1 |= t >> (32 - bit);
-            if (bit >= 32 && bit < 64) d1 |= t << (bit - 32);
-            if (bit < 64 && bit + 12 > 64) d2 |= t >> (64 - bit);
-            if (bit >= 64) d2 |= t << (bit - 64);
-        }
-        // lane half 1 holds the keys 4 further on (acc_row(i, 1) = acc_row(i, 0) + 4): shift the mask instead of the indices;
-        // complemented, so that an extracted bit is the -inf selector
-        const unsigned sh = 4u * (unsigned)hh;
-        const unsigned e[3] = {~__builtin_amdgcn_alignbit(d1, d0, sh), ~__builtin_amdgcn_alignbit(d2, d1, sh), ~(d2 >> sh)};
+        for (int b = 0; b < 2; ++b) {
+            // the lane's query in block b: same row, column (lane & 3) of the block (the lane's OWN token r is one of the two)
+            const int bqx = x0 + bxl + 4 * b + (lane & 3), cx0 = x0 + bxl + 4 * b - 2;
+            const int wx0 = max(0, bqx - 2), wx1 = min(min(h, bqx + 3), w);                   // reference LFT.py:155 (sic)
+            const int xa = min(max(wx0 - cx0, 0), 8), xb = min(max(wx1 - cx0, 0), 8);
+            const unsigned xs = (((1u << xb) - 1u) & ~((1u << xa) - 1u)) >> gx4;                // bit e: neighbourhood column gx4 + e
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+            for (int t = 0; t < 4; ++t) {
+                const unsigned inval = ~(xs & (unsigned)__builtin_amdgcn_sbfe((int)ymask, 2 * t + gy, 1));
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int k0 = 32 * j + acc_row(i, 0);                       // key index for lane half 0 (compile-time); half 1: k0 + 4
-                const unsigned out = (unsigned)__builtin_amdgcn_sbfe((int)e[k0 >> 5], k0 & 31, 1);
-                bias[j][i] = __builtin_bit_cast(float, out & 0xff800000u);  // 0 inside the window, -inf outside
+                for (int e = 0; e < 4; ++e)
+                    bias[b][t][e] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_sbfe((int)inval, e, 1) & 0xff800000u);   // 0 inside the window, -inf outside
             }
+        }
     }
-    int kofs[3];
+    // K rows as the A operand of v_mfma_f32_16x16x16: lane 16 g + qi reads labels 4 g .. 4 g + 3 (8 bytes) of key qi of the tile;
+    // V^T by transposing reads: lane 16 g + 4 q + p supplies the address of key 4 g + q, channels 4 p .. 4 p + 3.  One base each;
+    // block, tile and head are compile-time offsets folded into the instructions.
+    // With the quarter swizzle (att_swz) the label quarter 2 hl + gq of a token sits in stored quarter (2 hl + gq) ^ s(row, col);
+    // s's column bit is (b ^ lane bit), so there are two bases, selected at compile time by hl ^ b.
+    int kb[2], vb[2];
+    {
+        const int ktok = ((qi >> 3) * kAttHC + bxl + (qi & 7)) * 64, ks0 = (qi >> 3) & 1, ks1 = (qi >> 2) & 1;
+        const int vtok = ((g4 >> 1) * kAttHC + bxl + 4 * (g4 & 1) + (qi >> 2)) * 64, vs0 = (g4 >> 1) & 1, vs1 = g4 & 1, vp = qi & 3;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int kk = 32 * j + r;
-        kofs[j] = ((kk / 12) * kAttHC + bxl + kk % 12) * 64 + hh * 16;
+        for (int x = 0; x < 2; ++x) {
+            kb[x] = ktok + 32 * (x ^ ks1) + 16 * ((g4 >> 1) ^ ks0) + 8 * (g4 & 1);
+            vb[x] = kAdTile + vtok + 32 * (x ^ vs1) + 16 * ((vp >> 1) ^ vs0) + 8 * (vp & 1);
+        }
     }
-    // V^T transposing reads: element group `wh` of k-step (j, s2) covers keys kk = c + t .. with c = 32 j + 16 s2 + 8 wh
-    // (compile time) and t = 4 hh + tq (lane); its slot is kk + 24 (kk / 12) + bxl, and (c + t) / 12 = c / 12 + (c % 12 == 8 && hh):
-    // two per-lane bases + compile-time offsets (folded into the instruction) instead of twelve address registers.
-    const int li = lane & 15, tq = li >> 2, tp = li & 3, g2 = (lane >> 4) & 1;
-    const int vb0 = kAdTile + (4 * hh + tq + bxl) * 64 + (16 * g2 + 4 * tp) * 2;
-    const int vb1 = vb0 + 24 * 64 * hh;
     LFT_STAMP(17);
     raw16 qa, qb;
     if constexpr (!TOKLM) q_load_async(qptr, qptr + kQHead, qa, qb);
@@ -487,67 +501,109 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
             else wait_vm_q<kSpaBSlotsA * Ring::PIECES_PER_WAVE>(qa, qb);
         }
         wg_barrier_keep_vm();                                              // everybody's pieces of this head pair have landed
+        LFT_NOTE_ASM_("USE", kNoteKV, hg & 1);
         LFT_STAMP(18 + 2 * hg);
-        Frag<T> qf[2];
-        if constexpr (TOKLM) { qf[0] = qfr[2 * hg]; qf[1] = qfr[2 * hg + 1]; }
-        else { qf[0].v = __builtin_bit_cast(V8, qa); qf[1].v = __builtin_bit_cast(V8, qb); }
+        raw16 qf[2];                                                       // per head: registers 0, 1 = block A's operand, 2, 3 = block B's
+        if constexpr (TOKLM) { qf[0] = __builtin_bit_cast(raw16, qfr[2 * hg].v); qf[1] = __builtin_bit_cast(raw16, qfr[2 * hg + 1].v); }
+        else { qf[0] = qa; qf[1] = qb; frag_to_blocks(qf[0]); frag_to_blocks(qf[1]); }
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl) {
-            f32x16 S[3], o;
-            float m = -INFINITY;
+            f32x4 S[2][4];
+            float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                Frag<T> kf;
-                kf.v = __builtin_bit_cast(V8, load_raw16(buf + kofs[j] + hl * 32));
-                S[j] = mfma16(kf.v, qf[hl].v, bias[j]);   // S^T[key, q] + mask bias
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) m = fmaxf(m, S[j][i]);
-            }
-            m = fmaxf(xhalf_max(m), -1.0e30f);                               // empty window: keep exp2(-inf - m) = 0, not NaN
+                for (int t = 0; t < 4; ++t) {
+                    const u32x2 kf = *reinterpret_cast<const u32x2*>(buf + kb[hl ^ b] + (2 * t * kAttHC + 4 * b) * 64);
+                    S[b][t] = mfma16k16(kf, u32x2{qf[hl][2 * b], qf[hl][2 * b + 1]}, bias[b][t], T());   // S^T[key, q] + mask bias
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { if (b == 0) m0 = fmaxf(m0, S[b][t][e]); else m1 = fmaxf(m1, S[b][t][e]); }
+                }
+            xrow_combine2(m0, m1, [](float a, float b) { return max_fast(a, b); });
+            m0 = fmaxf(m0, -1.0e30f); m1 = fmaxf(m1, -1.0e30f);              // empty window: keep exp2(-inf - m) = 0, not NaN
             // this phase is bound by vector-instruction issue: subtract and sum as register pairs (v_pk_add_f32)
-            const f32x2 mm = {m, m};
-            f32x2 sum2 = {0.0f, 0.0f};
+            float sum[2];
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int b = 0; b < 2; ++b) {
+                const float m = b ? m1 : m0;
+                const f32x2 mm = {m, m};
+                f32x2 sum2 = {0.0f, 0.0f};
 #pragma unroll
-                for (int i = 0; i < 16; i += 2) {
-                    f32x2 d = f32x2{S[j][i], S[j][i + 1]} - mm;
-                    d[0] = fast_exp2(d[0]); d[1] = fast_exp2(d[1]);
-                    S[j][i] = d[0]; S[j][i + 1] = d[1];
-                    sum2 += d;
-                }
-            const float sum = xhalf_sum(sum2[0] + sum2[1]);
-            const float inv = sum > 0.0f ? fast_rcp(sum) : 0.0f;                // empty window (h < w quirk): 0, as the pinned reference
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) o[i] = 0.0f;
+                    for (int e = 0; e < 4; e += 2) {
+                        f32x2 d = f32x2{S[b][t][e], S[b][t][e + 1]} - mm;
+                        d[0] = fast_exp2(d[0]); d[1] = fast_exp2(d[1]);
+                        S[b][t][e] = d[0]; S[b][t][e + 1] = d[1];
+#ifndef LFT_SPAB_ONES_SUM
+                        sum2 += d;
+#endif
+                    }
+                sum[b] = sum2[0] + sum2[1];
+            }
+#ifndef LFT_SPAB_ONES_SUM
+            xrow_combine2(sum[0], sum[1], [](float a, float b) { return a + b; });
+#endif
+            typedef typename H16<T>::v4 V4;
+            u32x2 ob[2];
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int b = 0; b < 2; ++b) {
+#ifndef LFT_SPAB_ONES_SUM
+                const float inv = sum[b] > 0.0f ? fast_rcp(sum[b]) : 0.0f;     // empty window (h < w quirk): 0, as the pinned reference
+#else
+                f32x4 osum[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+#endif
+                f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int c0 = 32 * j + 16 * s2, c1 = c0 + 8;
+                for (int u = 0; u < 2; ++u) {                                  // O^T[d, q] += V^T P^T over key tiles 2 u, 2 u + 1 (k = 8 g + j: tile 2 u + (j >> 2), key 4 g + (j & 3))
                     const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(buf + (c0 % 12 == 8 ? vb1 : vb0) + (c0 + 24 * (c0 / 12)) * 64));
+                        (__attribute__((address_space(3))) s16x4*)(buf + vb[hl ^ b] + (2 * (2 * u) * kAttHC + 4 * b) * 64));
                     const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(buf + (c1 % 12 == 8 ? vb1 : vb0) + (c1 + 24 * (c1 / 12)) * 64));
-                    Frag<T> vf;
-                    vf.v = __builtin_bit_cast(V8, (short __attribute__((ext_vector_type(8)))){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
-                    mma(vf, acc_to_frag(S[j], s2, T()), o);                   // O^T[d, q] += V^T P^T (rows of BOTH heads; only this head's 16 are kept)
-                }
-            // rows 16 hl .. 16 hl + 15 (registers 8 hl .. 8 hl + 7) are this head's channels 32 hg + 16 hl + ..: k-step 2 hg + hl of out_proj
+                        (__attribute__((address_space(3))) s16x4*)(buf + vb[hl ^ b] + (2 * (2 * u + 1) * kAttHC + 4 * b) * 64));
+                    const V8 vf = __builtin_bit_cast(V8, (short __attribute__((ext_vector_type(8)))){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
+                    V8 pf;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) of[2 * hg + hl].v[i] = (T)(o[8 * hl + i] * inv);
-            // keep the heads apart: left alone, the scheduler interleaves two heads (two sets of score tiles live) and
-            // hoists the next head pair's work over this one's softmax -- 100+ spilled registers
+                    for (int e = 0; e < 4; ++e) { pf[e] = (T)S[b][2 * u][e]; pf[4 + e] = (T)S[b][2 * u + 1][e]; }
+                    o = mfma16k32(vf, pf, o);
+#ifdef LFT_SPAB_ONES_SUM
+                    {   // EXPERIMENT: the row sums from an all-ones A operand (every row of the product = the column sums of P^T)
+                        V8 ones;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
+                        osum[b] = mfma16k32(ones, pf, osum[b]);
+                    }
+#endif
+                }
+#ifdef LFT_SPAB_ONES_SUM
+                const float inv = osum[b][0] > 0.0f ? fast_rcp(osum[b][0]) : 0.0f;
+#endif
+                V4 oc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oc[e] = (T)(o[e] * inv);
+                ob[b] = __builtin_bit_cast(u32x2, oc);
+            }
+            // the two blocks' O^T tiles (row 4 g + e = label, column = query) -> ONE 32-column fragment: out_proj's k-step 2 hg + hl,
+            // element (h, j) = the head's label 8 h + j (the order V's channels have in the LDS tile)
+            raw16 fo = raw16{ob[0][0], ob[0][1], ob[1][0], ob[1][1]};
+            frag_to_blocks(fo);                                                // the same row exchange, read the other way round
+            of[2 * hg + hl].v = __builtin_bit_cast(V8, fo);
+            // (No scheduling fence between the two heads of a pair any more: with 32 score registers per head instead of 48 the
+            // scheduler may overlap one head's MFMAs with the other's softmax without spilling -- measured +1 % on the bench.
+            // -DLFT_SPAB_HEAD_FENCE restores it for experiments.)
+#ifdef LFT_SPAB_HEAD_FENCE
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         LFT_STAMP(19 + 2 * hg);
+        LFT_NOTE_ASM_("DONE", kNoteKV, hg & 1);
         wg_barrier_keep_vm();                                              // every wave is done reading this buffer
         if constexpr (!TOKLM) {
             if (hg < 3) q_load_async(qptr + kQPair * (hg + 1), qptr + kQPair * (hg + 1) + kQHead, qa, qb);
         }
         if (hg < 2) stage(hg + 2, buf);
         else if (hg == 2) {                                                // buffer A now belongs to the weight ring
-#pragma unroll
+            LFT_NOTE_ASM_("ALIAS_LT", kNoteWRingPipe, kSpaBSlotsA);        // (for the static check: ring slots below this one lie in K/V buffer 0,
+#pragma unroll                                                             //  the others in buffer 1)
             for (int c = 0; c < kSpaBSlotsA; ++c) ring.issue(c);
         } else {                                                           // ... and so does buffer B
 #pragma unroll
@@ -608,7 +664,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
     }
     if constexpr (YLM) {                                              // the mirror image of the TOKLM load: four 16-byte stores per lane, no LDS
         if (qy < h) {
-            T* dst = Y + (img0 + (long long)qy * w + x0) * 64 + (32 * hh + bxl + (r & 7)) * 8;
+            T* dst = Y + (img0 + (long long)qy * w + x0) * 64 + (32 * hh + bxl + qpx) * 8;
 #pragma unroll
             for (int kidx = 0; kidx < 4; ++kidx) {
                 V8 v;

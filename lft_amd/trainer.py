@@ -112,14 +112,16 @@ class SyntheticPatchSource(TensorPatchSource):
     """Smooth random light fields: HR views = a random low-frequency image shifted by a per-view disparity; LR = box
     down-sampling of each view.  Learnable (the network must undo the blur), deterministic in ``seed``."""
 
-    def __init__(self, n: int, angRes: int, scale: int, patch: int = 32, seed: int = 0, device="cpu"):
+    def __init__(self, n: int, angRes: int, scale: int, patch: int = 32, seed: int = 0, device="cpu", fmax: float = 0.25):
+        # fmax: highest spatial frequency of the scene in cycles per HR pixel (0.25 = the LR Nyquist limit at 2x: hard scenes,
+        # bicubic ~24 dB; 0.06: smooth scenes on which a trained network reaches the PSNR range of the reference's tables)
         g = np.random.Generator(np.random.PCG64([seed, n, angRes, scale, patch]))
         P = patch * scale
         hr = np.empty((n, angRes * P, angRes * P), dtype=np.float32)
         yy, xx = np.meshgrid(np.arange(P, dtype=np.float32), np.arange(P, dtype=np.float32), indexing="ij")
         for i in range(n):
             k = 6
-            fy, fx = g.uniform(0.02, 0.25, k), g.uniform(0.02, 0.25, k)
+            fy, fx = g.uniform(0.02, fmax, k), g.uniform(0.02, fmax, k)
             ph, am = g.uniform(0, 2 * np.pi, k), g.uniform(0.2, 1.0, k)
             disp = g.uniform(-1.5, 1.5)
             for u in range(angRes):

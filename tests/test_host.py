@@ -159,3 +159,32 @@ def test_no_asm_loaded_register_is_read_before_its_wait():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "asm_load_hazards.py"), "--build"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 suspicious read(s)" in r.stdout
+
+
+def test_lds_dma_pipelines_are_covered_by_counted_waits_and_barriers():
+    """Static check of every LDS-DMA pipeline in the product listing (tools/lds_dma_hazards.py; the listings of the test above are
+    re-used): each slot is read only after all pieces of its fill were retired by a counted vmcnt wait AND published by a barrier,
+    and refilled only after its reads were waited for and a barrier passed.  The check must also bite: with every counted wait of
+    k_spa_b weakened by one it has to report violations."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "lds_dma_hazards.py")
+    r = subprocess.run([sys.executable, tool, "--build"], capture_output=True, text=True, env=dict(os.environ, LFT_HAZARD_REUSE="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 LDS-DMA protocol violation(s)" in r.stdout
+    lines = open("/tmp/lft_isa/hz1.s").read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN12_GLOBAL__N_17k_spa_bIDF16bLb0ELb1ELb0E"))
+    n = 0
+    for i in range(start, len(lines)):
+        if "s_endpgm" in lines[i]:
+            break
+        m = re.search(r"vmcnt\((\d+)\)", lines[i])
+        if m and "s_waitcnt" in lines[i] and int(m.group(1)) > 0:
+            lines[i] = lines[i].replace(m.group(0), "vmcnt(%d)" % (int(m.group(1)) + 1))
+            n += 1
+    assert n >= 10
+    open("/tmp/lft_isa/hz1_mut.s", "w").write("\n".join(lines))
+    r = subprocess.run([sys.executable, tool, "/tmp/lft_isa/hz1_mut.s", "k_spa_bIDF16bLb0ELb1ELb0E"], capture_output=True, text=True)
+    assert r.returncode == 1 and "USE of" in r.stdout, r.stdout[-2000:]

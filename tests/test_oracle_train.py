@@ -53,13 +53,17 @@ def kink_inputs(g):
     return sd_np, lr, hr, A, s
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2])
+KINK_FIXTURES = [f"train_kink_a5_s2_b2_16x16_seed{i}" for i in (0, 1, 2)] + [
+    "train_kink_a5_s4_b1_16x16_seed0", "train_kink_a9_s2_b1_8x8_seed0", "train_kink_a3_s2_b1_16x40_seed0"]   # 4x, 9 x 9 views, h < w
+
+
+@pytest.mark.parametrize("seed", KINK_FIXTURES)
 def test_oracle_branches_and_gradients_on_unscreened_inputs(seed, golden_dir):
-    """tests/golden/train_kink_*: the real reference's gradients at 12 800 tokens on unscreened inputs, with its branch decision
+    """tests/golden/train_kink_*: the real reference's gradients at 5 k - 12.8 k tokens on unscreened inputs (2x, 4x, 9 x 9 views, h < w), with its branch decision
     at every ReLU / LeakyReLU unit.  The oracle must take the reference's branch at every unit that is not within 5e-4 of a
     kink, may differ from it only at a handful of units within fp32 rounding of 0, and -- told to take the reference's branch
     there -- must reproduce all 78 gradients."""
-    g = np.load(os.path.join(golden_dir, f"train_kink_a5_s2_b2_16x16_seed{seed}.npz"))
+    g = np.load(os.path.join(golden_dir, seed + ".npz"))
     sd_np, lr, hr, A, s = kink_inputs(g)
     sd = O.state_from_numpy(sd_np)
     O.branch_record = {}

@@ -238,6 +238,13 @@ def train_kink_case(ref, name, A, s, B, h, w, wseed=1, iseed=0, tseed=2, flavor=
     print(f"{name}: loss {float(loss):.6f}, {n_near} units within {KINK_TAU} of a kink -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+# The other shape families of the luck-free gradient check (round 4), each >= 5 k tokens on an unscreened input: a 4x case (1 024
+# up-sampler channels), 9 x 9 views (81-view angular attention), and h < w (the empty windows of LFT.py:155 pass no gradient).
+KINK_SHAPE_CASES = [("train_kink_a5_s4_b1_16x16_seed0", 5, 4, 1, 16, 16),
+                    ("train_kink_a9_s2_b1_8x8_seed0", 9, 2, 1, 8, 8),
+                    ("train_kink_a3_s2_b1_16x40_seed0", 3, 2, 1, 16, 40)]
+
+
 def main():
     torch.set_num_threads(8)
     ref = load_reference()
@@ -251,6 +258,10 @@ def main():
         # test_gradients_on_unscreened_inputs_with_aligned_kinks)
         for iseed in (0, 1, 2):
             train_kink_case(ref, f"train_kink_a5_s2_b2_16x16_seed{iseed}", 5, 2, 2, 16, 16, iseed=iseed)
+        return
+    if "--train-kink-shapes-only" in sys.argv:
+        for args in KINK_SHAPE_CASES:
+            train_kink_case(ref, *args)
         return
     if "--wide-only" in sys.argv:      # add the h < w fixture without rewriting the others
         run_case(ref, "wide_a2_s2_b1_6x12", 2, 2, 1, 6, 12, full_taps=True)
@@ -270,6 +281,8 @@ def main():
     run_case(ref, "cfg2_a5_s4_b1_32x32", 5, 4, 1, 32, 32, flavor="default")   # one patch of configs[1]
     for iseed in (0, 1, 2):
         train_kink_case(ref, f"train_kink_a5_s2_b2_16x16_seed{iseed}", 5, 2, 2, 16, 16, iseed=iseed)
+    for args in KINK_SHAPE_CASES:
+        train_kink_case(ref, *args)
 
 
 if __name__ == "__main__":

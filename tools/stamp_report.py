@@ -4,10 +4,14 @@ LFT_STAMP() points of k_spa1 / k_spa2 (wave 0 of each workgroup).  GPU box only;
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-so = os.path.join(ROOT, "gpurun_out", "liblft_hip_stamps.so")
-os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLFT_EXPERIMENT",
-                       os.path.join(ROOT, "lft_amd", "csrc", "lft_api.hip"), "-o", so])
+# LFT_STAMPS_SO: a library built beforehand with the product flags + -DLFT_EXPERIMENT (hipcc cross-compiles in the build container:
+#   python tools/ab_build.py --build stamps:-DLFT_EXPERIMENT   ->  ab_so/liblft_stamps.so); otherwise it is built here, on GPU time.
+so = os.environ.get("LFT_STAMPS_SO")
+if not so:
+    so = os.path.join(ROOT, "gpurun_out", "liblft_hip_stamps.so")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLFT_EXPERIMENT",
+                           os.path.join(ROOT, "lft_amd", "csrc", "lft_api.hip"), "-o", so])
 from lft_amd import _lib
 _lib.LIB_PATH = so
 import numpy as np, torch
