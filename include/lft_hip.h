@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LFT_ABI_VERSION 4
+#define LFT_ABI_VERSION 5
 #define LFT_PREC_F32 0
 #define LFT_PREC_BF16 1
 #define LFT_PREC_F16 2
@@ -132,9 +132,8 @@ int lft_scene_integrate(const float* sr_patches, float* sr_scene, int A, int h0,
  * lft_train_backward: dout [B,1,A*h*s,A*w*s] -> grads = ONE flat fp32 buffer (lft_train_grad_floats) holding the 78
  *                     parameter gradients back to back in state_dict order, fully overwritten (not accumulated).
  *                     A data-parallel job all-reduces this one buffer.  No gradient flows to lr.
- *                     side_stream: accepted for ABI compatibility and ignored since ABI 4 -- the gradient tensors of the pass live
- *                     in an arena of the tape and are re-used as they die, which needs every kernel on ONE stream (round 2 ran
- *                     the weight-gradient kernels on it: +3 % speed for twice the tape).
+ *                     Every kernel of the pass runs on `stream` (its gradient tensors live in an arena of the tape and are re-used as
+ *                     they die; ABI 4 still carried the second stream of round 2 as an ignored argument -- gone in ABI 5).
  * lft_train_tape_offset: float offset of a saved activation inside the tape, for tests ("feat", "ang0.y", "spa2.tok", ...). */
 int lft_train_tape_bytes(int B, int A, int h, int w, int s, size_t* out_bytes);
 int lft_train_grad_floats(int s, size_t* out_floats);
@@ -142,14 +141,14 @@ int lft_train_tape_offset(const char* name, int B, int A, int h, int w, int s, s
 int lft_train_forward(const float* const* params, int nparams, const float* lr, float* out, void* tape,
                       int B, int A, int h, int w, int s, int math, void* stream);
 int lft_train_backward(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
-                       int B, int A, int h, int w, int s, int math, void* stream, void* side_stream);
+                       int B, int A, int h, int w, int s, int math, void* stream);
 /* The same pass for data-parallel training (the reference's DP recipe, SURVEY.md section 8e: gradients summed over ranks):
  * the flat gradient buffer is finished in LFT_GRAD_BUCKETS contiguous ranges, in this order --
  *   bucket 0: altblock.2, altblock.3, upsampling   (after the backward of layer 2)
  *   bucket 1: altblock.0, altblock.1               (after layer 0)
  *   bucket 2: conv_init0, conv_init                (end of the pass)
  * -- and on_bucket(user, bucket, first_float, n_floats) is called ON THE HOST, from inside this call, right after the last
- * kernel writing that range has been enqueued on `stream` (the weight-gradient side stream joined).  The caller orders a
+ * kernel writing that range has been enqueued on `stream`.  The caller orders a
  * communication stream after `stream` there and starts the bucket's all-reduce, which then runs beside the kernels of the
  * remaining buckets; or, while capturing, ends one graph and begins the next (lft_amd/train.py does the latter).  Nothing
  * enqueued after the callback touches the bucket's range.  The callback returns 0 to continue; any other value stops the pass
@@ -158,9 +157,26 @@ int lft_train_backward(const float* const* params, int nparams, const float* lr,
 #define LFT_GRAD_BUCKETS 3
 typedef int (*lft_bucket_fn)(void* user, int bucket, size_t first_float, size_t n_floats);
 int lft_train_backward_buckets(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
-                               int B, int A, int h, int w, int s, int math, void* stream, void* side_stream,
+                               int B, int A, int h, int w, int s, int math, void* stream,
                                lft_bucket_fn on_bucket, void* user);
 int lft_train_grad_bucket(int s, int bucket, size_t* first_float, size_t* n_floats);
+/* The backward pass of ONE block, for unit tests of the backward kernels (the `_bwd` counterparts of the per-stage forward entry
+ * points above).  `tape` must hold a complete lft_train_forward of the same inputs.  The block's incoming
+ * gradient d_out and outgoing gradient d_in are caller buffers; only the block's own parameter gradients are written to `grads`
+ * (the flat buffer of lft_train_backward; every other range is left untouched).
+ *   LFT_BLOCK_UPSAMPLE : d_out = d loss / d output image [B,1,A*h*s,A*w*s]; d_in = gradient of the body features [N,64]
+ *                        (reference LFT.py:79-81; gradients of upsampling.0.weight, upsampling.3.weight)
+ *   LFT_BLOCK_SPA      : SpaTrans of `layer` (LFT.py:176-191): d_out, d_in [N,64]
+ *   LFT_BLOCK_ANG      : AngTrans of `layer` (LFT.py:225-238): d_out, d_in [N,64]
+ *   LFT_BLOCK_INIT     : conv_init0 + conv_init + residual (LFT.py:65-66): d_out = gradient of the features [N,64]; d_in unused (may be NULL)
+ * N = B*A*A*h*w tokens, channels-last [B, A*A, h, w, 64] fp32. */
+#define LFT_BLOCK_UPSAMPLE 0
+#define LFT_BLOCK_SPA 1
+#define LFT_BLOCK_ANG 2
+#define LFT_BLOCK_INIT 3
+int lft_train_block_backward(const float* const* params, int nparams, const float* lr, void* tape, int block, int layer,
+                             const float* d_out, float* d_in, float* grads,
+                             int B, int A, int h, int w, int s, int math, void* stream);
 /* Profiling aid, NOT for the hot path (bench.py's `train.roofline`): lft_train_forward + lft_train_backward on ONE stream with a HIP
  * event after every kernel; SYNCHRONISES the stream and returns per-kernel milliseconds in launch order (host arrays of max_records
  * entries, names are static strings; a step has about 450 launches). */
@@ -184,12 +200,6 @@ int lft_adam_step(float* p, const float* g, float* m, float* v, long long n, flo
 int lft_view_metrics_scratch_bytes(int B, int A, int h, int w, size_t* out_bytes);
 int lft_view_metrics(const float* label, const float* out, int B, int A, int h, int w, float ssim_range, float* psnr, float* ssim,
                      void* scratch, void* stream);
-
-/* Debug aid: a single conv_init[which] launch (with_res: add `res`; extra_lds: pad the LDS request). */
-int lft_debug_conv64(const void* packed, int which, int with_res, const void* in, const void* res, void* out,
-                     int B, int A, int h, int w, int s, int prec, int extra_lds, void* stream);
-/* MFMA fragment-layout self test: C = Am[32x16] * Bm[16x32], D = W2[32x32] * C.  All fp32 device buffers. */
-int lft_mfma_selftest(const float* Am, const float* Bm, const float* W2, float* C, float* D, int prec, void* stream);
 
 #ifdef __cplusplus
 }

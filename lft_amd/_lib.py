@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("LFT_LIB_PATH") or os.path.join(HERE, "liblft_hip.so")   # LFT_LIB_PATH: experiment builds (tools/ab_build.py)
 SOURCES = ["lft_api.hip", "lft_common.cuh", "lft_kernels_a.cuh", "lft_kernels_b.cuh", "lft_train.cuh", "lft_train_host.cuh", "lft_metrics.cuh"]
-ABI_VERSION = 4                      # LFT_ABI_VERSION of include/lft_hip.h: lib() refuses a library that reports another one
+ABI_VERSION = 5                      # LFT_ABI_VERSION of include/lft_hip.h: lib() refuses a library that reports another one
 STATUS_NONFINITE = 1001              # LFT_STATUS_NONFINITE
 
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
@@ -130,9 +130,11 @@ _SIGS = {
     "lft_train_grad_floats": (c_int, [c_int, POINTER(c_size_t)]),
     "lft_train_tape_offset": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "lft_train_forward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "lft_train_backward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "lft_train_backward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lft_train_backward_buckets": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                           c_void_p, c_void_p, c_void_p, c_void_p]),
+                                           c_void_p, c_void_p, c_void_p]),
+    "lft_train_block_backward": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lft_train_grad_bucket": (c_int, [c_int, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     "lft_train_step_profiled": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p, c_int, POINTER(c_float), POINTER(c_char_p), POINTER(c_int)]),
@@ -140,10 +142,13 @@ _SIGS = {
     "lft_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_void_p]),
     "lft_view_metrics_scratch_bytes": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "lft_view_metrics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    # test-only entry points (include/lft_hip_test.h)
     "lft_debug_conv64": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lft_mfma_selftest": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
+TEST_EXPORTS = ("lft_debug_conv64", "lft_mfma_selftest")         # declared in include/lft_hip_test.h, not in the product header
+BLOCK_UPSAMPLE, BLOCK_SPA, BLOCK_ANG, BLOCK_INIT = 0, 1, 2, 3    # LFT_BLOCK_* of include/lft_hip.h
 GRAD_BUCKETS = 3
 BUCKET_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_size_t, c_size_t)     # lft_bucket_fn of include/lft_hip.h: 0 = go on, else stop
 
@@ -158,9 +163,12 @@ def lib() -> ctypes.CDLL:
         L = ctypes.CDLL(LIB_PATH)
         L.lft_version.restype, L.lft_version.argtypes = c_int, []
         got = L.lft_version()
-        if got != ABI_VERSION:               # a stale or foreign LFT_LIB_PATH build: its entry points may take other arguments
+        # (tools/ab_build.py times inference kernels of older experiment builds: LFT_AB_ANY_ABI=1 lets it load them -- never set it elsewhere)
+        if got != ABI_VERSION and not (os.environ.get("LFT_AB_ANY_ABI") == "1" and os.environ.get("LFT_LIB_PATH")):   # a stale or foreign LFT_LIB_PATH build: its entry points may take other arguments
             raise LftError(f"{LIB_PATH} reports ABI version {got}, this binding needs {ABI_VERSION}: rebuild it (__graft_entry__.build())")
         for name, (res, args) in _SIGS.items():
+            if not hasattr(L, name) and got != ABI_VERSION:
+                continue                        # an older experiment build under LFT_AB_ANY_ABI
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
         _lib = L

@@ -10,6 +10,7 @@
 //   LFT_TU == 0   everything in one unit (tools, resource reports).
 // Every kernel and helper is local to its unit (anonymous namespace); the units share only the error buffer.
 #include "../../include/lft_hip.h"
+#include "../../include/lft_hip_test.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -867,18 +868,17 @@ int lft_train_forward(const float* const* params, int nparams, const float* lr, 
     return train_forward(params, lr, out, static_cast<float*>(tape), d, math, static_cast<hipStream_t>(stream));
 }
 int lft_train_backward(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
-                       int B, int A, int h, int w, int s, int math, void* stream, void* side_stream) {
+                       int B, int A, int h, int w, int s, int math, void* stream) {
     Dims d; int rc;
     if (!params || !lr || !tape || !dout || !grads) return fail(LFT_ERR_ARG, "null pointer");
     if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
     for (int i = 0; i < nparams; ++i) if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
     if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32 or LFT_MATH_BF16X3, got %d", math);
-    if (side_stream == stream) side_stream = nullptr;
-    return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, math, static_cast<hipStream_t>(stream), static_cast<hipStream_t>(side_stream));
+    return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, math, static_cast<hipStream_t>(stream));
 }
 int lft_train_backward_buckets(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
-                               int B, int A, int h, int w, int s, int math, void* stream, void* side_stream,
+                               int B, int A, int h, int w, int s, int math, void* stream,
                                lft_bucket_fn on_bucket, void* user) {
     Dims d; int rc;
     if (!params || !lr || !tape || !dout || !grads || !on_bucket) return fail(LFT_ERR_ARG, "null pointer");
@@ -886,9 +886,23 @@ int lft_train_backward_buckets(const float* const* params, int nparams, const fl
     for (int i = 0; i < nparams; ++i) if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
     if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32 or LFT_MATH_BF16X3, got %d", math);
-    if (side_stream == stream) side_stream = nullptr;
-    return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, math, static_cast<hipStream_t>(stream),
-                          static_cast<hipStream_t>(side_stream), on_bucket, user);
+    return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, math, static_cast<hipStream_t>(stream), on_bucket, user);
+}
+int lft_train_block_backward(const float* const* params, int nparams, const float* lr, void* tape, int block, int layer,
+                             const float* d_out, float* d_in, float* grads,
+                             int B, int A, int h, int w, int s, int math, void* stream) {
+    Dims d; int rc;
+    if (!params || !lr || !tape || !d_out || !grads) return fail(LFT_ERR_ARG, "null pointer");
+    if (block < LFT_BLOCK_UPSAMPLE || block > LFT_BLOCK_INIT) return fail(LFT_ERR_ARG, "block must be LFT_BLOCK_UPSAMPLE .. LFT_BLOCK_INIT, got %d", block);
+    if ((block == LFT_BLOCK_SPA || block == LFT_BLOCK_ANG) && (layer < 0 || layer >= kLayers)) return fail(LFT_ERR_ARG, "layer %d out of range", layer);
+    if (block != LFT_BLOCK_INIT && !d_in) return fail(LFT_ERR_ARG, "d_in is null");
+    if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
+    for (int i = 0; i < nparams; ++i) if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
+    if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
+    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32 or LFT_MATH_BF16X3, got %d", math);
+    const BlockSel sel{block, layer, d_out, d_in};
+    return train_backward(params, lr, static_cast<float*>(tape), block == LFT_BLOCK_UPSAMPLE ? d_out : nullptr, grads, d, math,
+                          static_cast<hipStream_t>(stream), nullptr, nullptr, false, nullptr, nullptr, &sel);
 }
 int lft_train_step_profiled(const float* const* params, int nparams, const float* lr, float* out, void* tape, const float* dout, float* grads,
                             int B, int A, int h, int w, int s, int math, void* stream, int max_records, float* ms_out, const char** names_out, int* n_out) {

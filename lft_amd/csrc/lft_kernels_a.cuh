@@ -111,6 +111,28 @@ __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, con
     // bank conflicts).  9 taps padded to 12 floats per channel = three 16-byte reads; channel groups 100 floats apart put the
     // eight distinct addresses of a 16-lane group on disjoint banks.
     __shared__ __attribute__((aligned(16))) float wl[8 * 100];
+    const int hw = h * w, im = blockIdx.y, V = A * A;
+    const int cg = threadIdx.x & 7;
+    const int b = im / V, v = im - b * V, a1 = v / A, a2 = v - a1 * A;
+    const float* img = lr + (size_t)b * (A * h) * (A * w) + (size_t)(a1 * h) * (A * w) + a2 * w;
+    // kConv0Tok tokens per workgroup, 32 per pass: the weight staging and the barrier above are paid once per 128 tokens
+    // (3 200 workgroups of 32 tokens spent most of their time in that prologue).
+    // The kernel is a latency chain, not a throughput problem (13 MB out, 60 MFLOP): round 4 issues the taps of ALL passes before
+    // the first use -- one memory round trip per workgroup instead of one per pass (four, each behind the previous pass's compute).
+    constexpr int NP = kConv0Tok / 32;
+    float val[NP][9];
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        const int p = min(blockIdx.x * kConv0Tok + pass * 32 + (int)(threadIdx.x >> 3), hw - 1);
+        const int y = p / w, x = p - y * w;
+        // branch-free: all nine taps are loaded from clamped (readable) positions, then selected -- a conditional load is a
+        // masked branch per tap, nine dependent round trips instead of nine loads in flight.
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            val[pass][t] = img[min(max(yy, 0), h - 1) * (A * w) + min(max(xx, 0), w - 1)];
+        }
+    }
     {   // all three loads of a thread in flight before the first LDS write (as a load / wait / write loop: three serialised round trips)
         float wv[3];
 #pragma unroll
@@ -122,31 +144,18 @@ __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, con
         }
     }
     __syncthreads();
-    const int hw = h * w, im = blockIdx.y, V = A * A;
-    const int cg = threadIdx.x & 7;
-    const int b = im / V, v = im - b * V, a1 = v / A, a2 = v - a1 * A;
-    const float* img = lr + (size_t)b * (A * h) * (A * w) + (size_t)(a1 * h) * (A * w) + a2 * w;
-    // kConv0Tok tokens per workgroup, 32 per pass: the weight staging and the barrier above are paid once per 128 tokens
-    // (3 200 workgroups of 32 tokens spent most of their time in that prologue)
 #pragma unroll
-    for (int pass = 0; pass < kConv0Tok / 32; ++pass) {
+    for (int pass = 0; pass < NP; ++pass) {
+        // The empty asm names a pass's nine values at once: it keeps hipcc from sinking the loads back under their conditions.
+        asm volatile("" : "+v"(val[pass][0]), "+v"(val[pass][1]), "+v"(val[pass][2]), "+v"(val[pass][3]), "+v"(val[pass][4]), "+v"(val[pass][5]),
+                          "+v"(val[pass][6]), "+v"(val[pass][7]), "+v"(val[pass][8]));
         const int p = blockIdx.x * kConv0Tok + pass * 32 + (threadIdx.x >> 3);
         if (p >= hw) return;
         const int y = p / w, x = p - y * w;
-        // branch-free: all nine taps are loaded from clamped (readable) positions, then selected -- a conditional load is a
-        // masked branch per tap, nine dependent round trips instead of nine loads in flight.  The empty asm names all nine
-        // values at once: it keeps hipcc from sinking the loads back under their conditions.
-        float val[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            val[t] = img[min(max(yy, 0), h - 1) * (A * w) + min(max(xx, 0), w - 1)];
-        }
-        asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]), "+v"(val[8]));
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            val[t] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? val[t] : 0.0f;
+            val[pass][t] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? val[pass][t] : 0.0f;
         }
         f32x4 o[2];
 #pragma unroll
@@ -155,10 +164,10 @@ __global__ __launch_bounds__(256) void k_conv0(const float* __restrict__ lr, con
             const f32x4 w03 = wq[0], w47 = wq[1], w8 = wq[2];
             float a = 0.0f;                                              // same order of additions as before: bit-identical results
 #pragma unroll
-            for (int t = 0; t < 4; ++t) a += w03[t] * val[t];
+            for (int t = 0; t < 4; ++t) a += w03[t] * val[pass][t];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) a += w47[t] * val[4 + t];
-            a += w8[0] * val[8];
+            for (int t = 0; t < 4; ++t) a += w47[t] * val[pass][4 + t];
+            a += w8[0] * val[pass][8];
             o[c >> 2][c & 3] = a;
         }
         T* row = out + ((size_t)im * hw + p) * 64 + cg * 8;

@@ -371,6 +371,51 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
     // Lane-major form (TOKLM): there are no query loads -- Q is COMPUTED in the prologue (below) -- and the iterations' waits
     // are the same counts without them:  [tok pe Wq01 D0 D1] wait(34) LN | wait(26) Q0 Wq2 | wait(26) Q1 Wq3 | wait(8) Q2 |
     // wait(0) Q3 | it0 .. D2 | it1: wait(9) .. D3 | it2: wait(9) .. R0-3 | it3: wait(8) ..
+    // Score tiles: per block b (columns bxl + 4 b ..) the 8 x 8 key neighbourhood = halo rows 0..7, halo columns bxl + 4 b .. + 7,
+    // cut into four 16-key tiles (tile t = halo rows 2 t, 2 t + 1, key kk -> row kk / 8, column kk % 8).  S^T[key, query] of tile
+    // (b, t): lane 16 g + qi holds query qi of block b against keys 4 g .. 4 g + 3 (register e), i.e. halo row 2 t + (g >> 1),
+    // neighbourhood columns 4 (g & 1) + e.  The 0 / -inf bias (window, image border, the `min(h, x+3)` quirk of LFT.py:155) is the
+    // product of a row mask and a column mask of the lane's query: one bit-field extract + AND per element.
+    const int g4 = lane >> 4, qi = lane & 15;
+    f32x4 bias[2][4];
+    int kb[2], vb[2];
+    auto setup_tiles = [&]() __attribute__((always_inline)) {
+    {
+        const int wy0 = max(0, qy - 2), wy1 = min(h, qy + 3), cy0 = y0 - 2;
+        const int ya = min(max(wy0 - cy0, 0), 8), yb = min(max(wy1 - cy0, 0), 8);
+        const unsigned ymask = ((1u << yb) - 1u) & ~((1u << ya) - 1u);     // halo rows inside the window (empty when yb <= ya)
+        const int gy = g4 >> 1, gx4 = 4 * (g4 & 1);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            // the lane's query in block b: same row, column (lane & 3) of the block (the lane's OWN token r is one of the two)
+            const int bqx = x0 + bxl + 4 * b + (lane & 3), cx0 = x0 + bxl + 4 * b - 2;
+            const int wx0 = max(0, bqx - 2), wx1 = min(min(h, bqx + 3), w);                   // reference LFT.py:155 (sic)
+            const int xa = min(max(wx0 - cx0, 0), 8), xb = min(max(wx1 - cx0, 0), 8);
+            const unsigned xs = (((1u << xb) - 1u) & ~((1u << xa) - 1u)) >> gx4;                // bit e: neighbourhood column gx4 + e
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const unsigned inval = ~(xs & (unsigned)__builtin_amdgcn_sbfe((int)ymask, 2 * t + gy, 1));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    bias[b][t][e] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_sbfe((int)inval, e, 1) & 0xff800000u);   // 0 inside the window, -inf outside
+            }
+        }
+    }
+    // K rows as the A operand of v_mfma_f32_16x16x16: lane 16 g + qi reads labels 4 g .. 4 g + 3 (8 bytes) of key qi of the tile;
+    // V^T by transposing reads: lane 16 g + 4 q + p supplies the address of key 4 g + q, channels 4 p .. 4 p + 3.  One base each;
+    // block, tile and head are compile-time offsets folded into the instructions.
+    // With the quarter swizzle (att_swz) the label quarter 2 hl + gq of a token sits in stored quarter (2 hl + gq) ^ s(row, col);
+    // s's column bit is (b ^ lane bit), so there are two bases, selected at compile time by hl ^ b.
+    {
+        const int ktok = ((qi >> 3) * kAttHC + bxl + (qi & 7)) * 64, ks0 = (qi >> 3) & 1, ks1 = (qi >> 2) & 1;
+        const int vtok = ((g4 >> 1) * kAttHC + bxl + 4 * (g4 & 1) + (qi >> 2)) * 64, vs0 = (g4 >> 1) & 1, vs1 = g4 & 1, vp = qi & 3;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            kb[x] = ktok + 32 * (x ^ ks1) + 16 * ((g4 >> 1) ^ ks0) + 8 * (g4 & 1);
+            vb[x] = kAdTile + vtok + 32 * (x ^ vs1) + 16 * ((vp >> 1) ^ vs0) + 8 * (vp & 1);
+        }
+    }
+    };
     unsigned bad = 0;                                                 // non-finite activation seen (layernorm_acc; published at the end)
     Frag<T> qfr[8];                                                   // TOKLM: this block's queries, all 8 heads, acc order
     raw16 tokr[8];                                                    // TOKLM: this lane's token pieces, kept packed for the residual of phase B
@@ -395,6 +440,13 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
         ld16_async_x8(wsrc + 8 * 1024, wqb);                              // head pair 1
         stage(0, bufA);
         stage(1, bufB);
+#ifdef LFT_SPAB_EARLY_SETUP
+        // EXPERIMENT (round 4, not adopted): the pure vector work that needs none of the data in flight (window bias tiles, LDS read
+        // bases: ~300 instructions) here, under the first memory round trip, instead of behind the Q projection.  With 52 asm loads
+        // pending and 32 more live registers hipcc spilled (132 B of scratch) and MOVED asm-loaded registers before their counted wait:
+        // tools/asm_load_hazards.py reports 57 reads of in-flight registers for this variant.  The block therefore stays behind Q.
+        setup_tiles();
+#endif
         // in flight: 2 + 16 + 16 + 18 = 52.  Tokens, position tokens and LayerNorm parameters first:
         wait_vm_8<16 + 2 * kAdPerWave>(tokr);
         wait_vm_8<16 + 2 * kAdPerWave>(per);
@@ -433,6 +485,9 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
         lnv = params_load(ln + 256, 256);
         stage(0, bufA);
         stage(1, bufB);
+#ifdef LFT_SPAB_EARLY_SETUP
+        setup_tiles();
+#endif
     }
     Ring ring;
     ring.setup(ws, smem, kSpaBSlotsA, 2 * kAdTile - kSpaBSlotsA * kSpaBChunk * 1024);
@@ -441,49 +496,9 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
     rows.nrow = max(0, min(4, h - y0)); rows.ncol = max(0, min(8, w - (x0 + bxl)));
     if (rows.ncol == 0) rows.nrow = 0;
     const long long tok0 = img0 + (long long)min(y0, h - 1) * w + min(x0 + bxl, w - 1);
-    // Score tiles: per block b (columns bxl + 4 b ..) the 8 x 8 key neighbourhood = halo rows 0..7, halo columns bxl + 4 b .. + 7,
-    // cut into four 16-key tiles (tile t = halo rows 2 t, 2 t + 1, key kk -> row kk / 8, column kk % 8).  S^T[key, query] of tile
-    // (b, t): lane 16 g + qi holds query qi of block b against keys 4 g .. 4 g + 3 (register e), i.e. halo row 2 t + (g >> 1),
-    // neighbourhood columns 4 (g & 1) + e.  The 0 / -inf bias (window, image border, the `min(h, x+3)` quirk of LFT.py:155) is the
-    // product of a row mask and a column mask of the lane's query: one bit-field extract + AND per element.
-    const int g4 = lane >> 4, qi = lane & 15;
-    f32x4 bias[2][4];
-    {
-        const int wy0 = max(0, qy - 2), wy1 = min(h, qy + 3), cy0 = y0 - 2;
-        const int ya = min(max(wy0 - cy0, 0), 8), yb = min(max(wy1 - cy0, 0), 8);
-        const unsigned ymask = ((1u << yb) - 1u) & ~((1u << ya) - 1u);     // halo rows inside the window (empty when yb <= ya)
-        const int gy = g4 >> 1, gx4 = 4 * (g4 & 1);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            // the lane's query in block b: same row, column (lane & 3) of the block (the lane's OWN token r is one of the two)
-            const int bqx = x0 + bxl + 4 * b + (lane & 3), cx0 = x0 + bxl + 4 * b - 2;
-            const int wx0 = max(0, bqx - 2), wx1 = min(min(h, bqx + 3), w);                   // reference LFT.py:155 (sic)
-            const int xa = min(max(wx0 - cx0, 0), 8), xb = min(max(wx1 - cx0, 0), 8);
-            const unsigned xs = (((1u << xb) - 1u) & ~((1u << xa) - 1u)) >> gx4;                // bit e: neighbourhood column gx4 + e
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const unsigned inval = ~(xs & (unsigned)__builtin_amdgcn_sbfe((int)ymask, 2 * t + gy, 1));
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    bias[b][t][e] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_sbfe((int)inval, e, 1) & 0xff800000u);   // 0 inside the window, -inf outside
-            }
-        }
-    }
-    // K rows as the A operand of v_mfma_f32_16x16x16: lane 16 g + qi reads labels 4 g .. 4 g + 3 (8 bytes) of key qi of the tile;
-    // V^T by transposing reads: lane 16 g + 4 q + p supplies the address of key 4 g + q, channels 4 p .. 4 p + 3.  One base each;
-    // block, tile and head are compile-time offsets folded into the instructions.
-    // With the quarter swizzle (att_swz) the label quarter 2 hl + gq of a token sits in stored quarter (2 hl + gq) ^ s(row, col);
-    // s's column bit is (b ^ lane bit), so there are two bases, selected at compile time by hl ^ b.
-    int kb[2], vb[2];
-    {
-        const int ktok = ((qi >> 3) * kAttHC + bxl + (qi & 7)) * 64, ks0 = (qi >> 3) & 1, ks1 = (qi >> 2) & 1;
-        const int vtok = ((g4 >> 1) * kAttHC + bxl + 4 * (g4 & 1) + (qi >> 2)) * 64, vs0 = (g4 >> 1) & 1, vs1 = g4 & 1, vp = qi & 3;
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            kb[x] = ktok + 32 * (x ^ ks1) + 16 * ((g4 >> 1) ^ ks0) + 8 * (g4 & 1);
-            vb[x] = kAdTile + vtok + 32 * (x ^ vs1) + 16 * ((vp >> 1) ^ vs0) + 8 * (vp & 1);
-        }
-    }
+#ifndef LFT_SPAB_EARLY_SETUP
+    setup_tiles();
+#endif
     LFT_STAMP(17);
     raw16 qa, qb;
     if constexpr (!TOKLM) q_load_async(qptr, qptr + kQHead, qa, qb);
@@ -535,20 +550,20 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
                         f32x2 d = f32x2{S[b][t][e], S[b][t][e + 1]} - mm;
                         d[0] = fast_exp2(d[0]); d[1] = fast_exp2(d[1]);
                         S[b][t][e] = d[0]; S[b][t][e + 1] = d[1];
-#ifndef LFT_SPAB_ONES_SUM
+#ifdef LFT_SPAB_VALU_SUM
                         sum2 += d;
 #endif
                     }
                 sum[b] = sum2[0] + sum2[1];
             }
-#ifndef LFT_SPAB_ONES_SUM
+#ifdef LFT_SPAB_VALU_SUM
             xrow_combine2(sum[0], sum[1], [](float a, float b) { return a + b; });
 #endif
             typedef typename H16<T>::v4 V4;
             u32x2 ob[2];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-#ifndef LFT_SPAB_ONES_SUM
+#ifdef LFT_SPAB_VALU_SUM
                 const float inv = sum[b] > 0.0f ? fast_rcp(sum[b]) : 0.0f;     // empty window (h < w quirk): 0, as the pinned reference
 #else
                 f32x4 osum[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
@@ -565,8 +580,11 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { pf[e] = (T)S[b][2 * u][e]; pf[4 + e] = (T)S[b][2 * u + 1][e]; }
                     o = mfma16k32(vf, pf, o);
-#ifdef LFT_SPAB_ONES_SUM
-                    {   // EXPERIMENT: the row sums from an all-ones A operand (every row of the product = the column sums of P^T)
+#ifndef LFT_SPAB_VALU_SUM
+                    {   // the softmax denominators from the matrix pipe: with an all-ones A operand every row of the product is the column
+                        // sum of P^T, i.e. each lane gets its query's sum over the tile pair's 32 keys with no cross-lane step (-16 packed
+                        // adds and one 7-instruction exchange per head for 4 small MFMAs; the sum is that of the ROUNDED probabilities, so
+                        // the weights that multiply V add up to 1 exactly).  -DLFT_SPAB_VALU_SUM: the vector-unit form.
                         V8 ones;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
@@ -574,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
                     }
 #endif
                 }
-#ifdef LFT_SPAB_ONES_SUM
+#ifndef LFT_SPAB_VALU_SUM
                 const float inv = osum[b][0] > 0.0f ? fast_rcp(osum[b][0]) : 0.0f;
 #endif
                 V4 oc;
@@ -788,15 +806,26 @@ __global__ __launch_bounds__(256) void k_assemble_t(const float* __restrict__ lr
     const int by0 = blockIdx.y * TL, bx0 = blockIdx.x * TL, b = blockIdx.z;
     const int hw = h * w, V = A * A;
     const float* Gb = G + (size_t)b * V * hw * gld;
-    for (int pidx = threadIdx.x; pidx < HL * HL * P4; pidx += 256) {
-        const int slot = pidx / P4, part = pidx - slot * P4;
-        const int by = by0 - 1 + slot / HL, bx = bx0 - 1 + slot % HL;
-        f32x4 v = f32x4{0, 0, 0, 0};                                   // outside the mosaic: zero padding of the final conv (LFT.py:43)
-        if (by >= 0 && by < MH && bx >= 0 && bx < MW) {
+    {   // every piece of the staging is requested before the first one is written to LDS (branch-free, from clamped addresses): one
+        // memory round trip per workgroup -- as a load / store loop with a conditional load it was four dependent ones
+        constexpr int NPC = HL * HL * P4, NIT = (NPC + 255) / 256;
+        f32x4 vv[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int pidx = min((int)threadIdx.x + 256 * i, NPC - 1);
+            const int slot = pidx / P4, part = pidx - slot * P4;
+            const int by = min(max(by0 - 1 + slot / HL, 0), MH - 1), bx = min(max(bx0 - 1 + slot % HL, 0), MW - 1);
             const int vy = by / h, py = by - vy * h, vx = bx / w, px = bx - vx * w;
-            v = load4(Gb + ((size_t)(vy * A + vx) * hw + py * w + px) * gld + part * 4);
+            vv[i] = load4(Gb + ((size_t)(vy * A + vx) * hw + py * w + px) * gld + part * 4);
         }
-        *reinterpret_cast<f32x4*>(gs + slot * GP + part * 4) = v;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int pidx = (int)threadIdx.x + 256 * i;
+            const int slot = pidx / P4, part = pidx - slot * P4;
+            const int by = by0 - 1 + slot / HL, bx = bx0 - 1 + slot % HL;
+            const bool in = by >= 0 && by < MH && bx >= 0 && bx < MW;  // outside the mosaic: zero padding of the final conv (LFT.py:43)
+            if (pidx < NPC) *reinterpret_cast<f32x4*>(gs + slot * GP + part * 4) = in ? vv[i] : f32x4{0, 0, 0, 0};
+        }
     }
     __syncthreads();
     unsigned bad = 0;                                                  // the network's output is the last place an overflow can show

@@ -382,10 +382,10 @@ int ang_attn(const TrainCtx& c, const float* QK, const float* Vv, float* O, cons
     const int V = c.d.V, npix = c.d.B * c.d.hw;
     int rc;
     if (V <= 32) {
-        const size_t lds = BWD ? (size_t)(4 * 8 * kAngHS<32> + 8 * 32 * 3) * 4 : (size_t)(2 * 8 * kAngHS<32>) * 4;
+        const size_t lds = BWD ? (size_t)(4 * 8 * kAngHS<32> + 8 * (32 * 3 + 1)) * 4 : (size_t)(2 * 8 * kAngHS<32>) * 4;
         k_ang_attn<32, BWD><<<npix, 256, lds, c.st>>>(QK, Vv, O, dO, dQK, dV, V, c.d.hw);
     } else {
-        const size_t lds = BWD ? (size_t)(4 * 8 * kAngHS<128> + 8 * 128 * 3) * 4 : (size_t)(2 * 8 * kAngHS<128>) * 4;
+        const size_t lds = BWD ? (size_t)(4 * 8 * kAngHS<128> + 8 * (128 * 3 + 1)) * 4 : (size_t)(2 * 8 * kAngHS<128>) * 4;
         if ((rc = allow_lds(k_ang_attn<128, BWD>, lds, "k_ang_attn"))) return rc;
         k_ang_attn<128, BWD><<<npix, 1024, lds, c.st>>>(QK, Vv, O, dO, dQK, dV, V, c.d.hw);
     }
@@ -510,9 +510,12 @@ struct BwdArena {
 };
 
 // dry: the allocation sequence only (P, lr, tape, dout, G may be null) -- returns the arena's peak through *peak_out.
+// One block of the pass on its own (lft_train_block_backward): its incoming gradient comes from the caller, its outgoing gradient
+// goes to the caller, only its own parameter gradients are produced.  The tape must hold a full forward.
+struct BlockSel { int block, layer; const float* d_out; float* d_in; };
 int train_backward(const float* const* P, const float* lr, float* tape, const float* dout, float* G, const Dims& d, int math,
-                   hipStream_t st, hipStream_t /*side: unused, kept for the ABI*/, BucketFn on_bucket = nullptr, void* user = nullptr,
-                   bool dry = false, size_t* peak_out = nullptr, size_t* part_peak_out = nullptr) {
+                   hipStream_t st, BucketFn on_bucket = nullptr, void* user = nullptr,
+                   bool dry = false, size_t* peak_out = nullptr, size_t* part_peak_out = nullptr, const BlockSel* sel = nullptr) {
     TrainLayout Tdry{};
     const TrainLayout T = dry ? Tdry : train_layout(d);
     if (T.rc) return T.rc;
@@ -570,6 +573,17 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
         return 0;
     };
 #define TRY(x) do { if ((rc = (x))) return rc; } while (0)
+    // Block selection (sel != null): `want(block, layer)` says whether a section runs; a selected section takes its incoming gradient
+    // from the caller and hands its result back through `give` (a device copy on the pass's stream), then the partial sums are reduced.
+    auto want = [&](int block, int layer) { return !sel || (sel->block == block && (block == LFT_BLOCK_UPSAMPLE || block == LFT_BLOCK_INIT || sel->layer == layer)); };
+    auto give = [&](const float* src, size_t floats) -> int {
+        if (!sel || !sel->d_in) return 0;
+        LFT_HIP_OK(hipMemcpyAsync(sel->d_in, src, floats * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return 0;
+    };
+    float* gskip = nullptr;
+    const float* dy = sel ? sel->d_out : nullptr;
+    if (want(LFT_BLOCK_UPSAMPLE, 0)) {
     // ---- up-sampler tail (the transpose of its forward: gather, GEMM with the overlap-add matrix) ----
     float* gu = c.F(T.gu);
     const int gt = (d.gp + 31) / 32;
@@ -583,13 +597,20 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
     TRY(run_lin(c, VW_UPM_B, 0, 0, dG, 32 * gt, 0, 0, nullptr, 0, gu, 64 * ss, N, c.F(T.act), 2));   // dU = (M^T dG) * lrelu'(U)
     A.put(dG);
     TRY(wgrad(c, gu, 64 * ss, c.F(T.body), 64, 1, g(P_UP0), 0, N));
-    float* gskip = nb(64);                                           // d body = d y3 = d feat (global skip): lives to the end of the pass
+    gskip = nb(64);                                                  // d body = d y3 = d feat (global skip): lives to the end of the pass
     TRY(lin_bwd(c, VW_UP_B, gu, nullptr, gskip, N));
-    const float* dy = gskip;
+    dy = gskip;
+    if (sel) {                                                       // the block on its own: fold dM now (the full pass does it at the end of bucket 0)
+        TRY(flush());
+        k_upm_fold<<<3, 256, 0, st>>>(dM, g(P_UP3), d.s);
+        LFT_LAUNCH_OK("k_upm_fold");
+        TRY(give(gskip, (size_t)N * 64));
+    }
+    }
     for (int l = kLayers - 1; l >= 0; --l) {
         // ================= SpaTrans backward: dy [N,64] -> dx =================
-        float* dx;
-        {
+        float* dx = nullptr;
+        if (want(LFT_BLOCK_SPA, l)) {
             const SpaTape& sp = T.spa[l];
             const float* xin = c.F(T.ang[l].y);
             float* gin = g(pidx(l, S_INPROJ));
@@ -640,9 +661,14 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
             dx = nb(64);
             TRY(lin_bwd(c, vw(l, MLP_B), dtok, nullptr, dx, N));
             A.put(dtok);
+            if (sel) { TRY(flush()); TRY(give(dx, (size_t)N * 64)); }
         }
         // ================= AngTrans backward: dx -> dy of the layer below =================
-        {
+        if (want(LFT_BLOCK_ANG, l)) {
+            if (sel) {                                               // the block on its own: its incoming gradient is the caller's (copied: the section releases dx)
+                dx = nb(64);
+                LFT_HIP_OK(hipMemcpyAsync(dx, sel->d_out, (size_t)N * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
             const AngTape& a = T.ang[l];
             const float* xin = l == 0 ? c.F(T.feat) : c.F(T.spa[l - 1].y);
             float* gin = g(pidx(l, A_INPROJ));
@@ -675,15 +701,26 @@ int train_backward(const float* const* P, const float* lr, float* tape, const fl
             TRY(ln_bwd(c, 64, xin, c.F(T.pe_ang), 1, P ? P[pidx(l, A_N1W)] : nullptr, dn, dxa, dxo, g(pidx(l, A_N1W)), g(pidx(l, A_N1B)), N));   // ... + d LN(x + PE)
             A.put(dn); A.put(dxa);
             dy = dxo;
+            if (sel) { TRY(flush()); TRY(give(dxo, (size_t)N * 64)); }
         }
+        if (sel) continue;
         if (l == 2) { TRY(end_bucket(0)); A.put(dM); }
         else if (l == 0) TRY(end_bucket(1));
         else TRY(flush());
     }
+    if (!want(LFT_BLOCK_INIT, 0)) {                                  // a single block other than the feature extractor: done
+        if (peak_out) *peak_out = A.peak;
+        if (part_peak_out) *part_peak_out = part_peak;
+        return 0;
+    }
     // ---- initial feature extractor ----
     float* dfeat = nb(64);
-    TRY(add3(c, dfeat, dy, gskip, N * 64));
-    A.put(dy); A.put(gskip);
+    if (sel) {                                                       // the block on its own: d feat is the caller's
+        LFT_HIP_OK(hipMemcpyAsync(dfeat, sel->d_out, (size_t)N * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+        TRY(add3(c, dfeat, dy, gskip, N * 64));
+        A.put(dy); A.put(gskip);
+    }
     float* dz3 = nb(64);
     TRY(act_bwd(c, dfeat, c.F(T.c3), dz3, N * 64, 2));
     TRY(wgrad(c, dz3, 64, c.F(T.c2), 64, 9, g(P_CONV + 2), 0, N));
@@ -721,7 +758,7 @@ BwdSizes bwd_sizes(const Dims& d) {
     static thread_local BwdSizes last_sz{};
     if (last_sz.arena && last.B == d.B && last.A == d.A && last.h == d.h && last.w == d.w && last.s == d.s) return last_sz;
     BwdSizes sz{};
-    sz.rc = train_backward(nullptr, nullptr, nullptr, nullptr, nullptr, d, LFT_MATH_F32, nullptr, nullptr, nullptr, nullptr, true, &sz.arena, &sz.part);
+    sz.rc = train_backward(nullptr, nullptr, nullptr, nullptr, nullptr, d, LFT_MATH_F32, nullptr, nullptr, nullptr, true, &sz.arena, &sz.part);
     if (sz.rc) { sz.arena = sz.part = 0; return sz; }             // not cached: the next call reports the failure again
     last = d; last_sz = sz;
     return sz;

@@ -216,7 +216,9 @@ class GraphedForward:
             torch.cuda.current_stream(example.device).wait_stream(s)
             torch.cuda.synchronize(example.device)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # thread-local capture errors: another thread's HIP calls (torch's NCCL watchdog polling its events under bench.py --gpus N)
+            # must not invalidate this capture (see lft_amd/train.py: CAPTURE_MODE)
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.static_out = net(self.static_in, _slot_base=slot_base)
             # The graph has the packed-weight buffer's address baked in: keep the buffer alive, and refuse to replay once
             # the module has dropped or replaced it, or once any parameter has changed since it was packed (optimizer step,

@@ -55,6 +55,11 @@ def _ptr_array(ps):
 
 
 MATH = {"fp32": _lib.MATH_F32, "bf16x3": _lib.MATH_BF16X3}
+# HIP-graph captures use the thread-local error mode: with a process group alive, torch's NCCL watchdog THREAD polls its work
+# events (hipEventQuery) at any time; under the default global mode such a call from another thread while this thread captures
+# invalidates the capture ("operation not permitted when stream is capturing" -- seen once in round 4 on the RCCL test, a race
+# that had been there since the graphs were introduced).  Only calls of the capturing thread itself matter to these captures.
+CAPTURE_MODE = "thread_local"
 
 
 def train_forward(ps, lr, A, s, tape=None, math="fp32"):
@@ -72,9 +77,8 @@ def train_forward(ps, lr, A, s, tape=None, math="fp32"):
     return out, tape
 
 
-def train_backward(ps, lr, tape, dout, A, s, grads=None, math="fp32", overlap=True):
-    """lft_train_backward: returns the flat gradient buffer (78 gradients back to back, state_dict order).  `overlap` is accepted
-    and ignored since ABI 4: the pass runs on one stream (its gradient tensors share an arena)."""
+def train_backward(ps, lr, tape, dout, A, s, grads=None, math="fp32"):
+    """lft_train_backward: returns the flat gradient buffer (78 gradients back to back, state_dict order)."""
     B, _, H, W = lr.shape
     h, w = H // A, W // A
     dev = lr.device
@@ -82,9 +86,24 @@ def train_backward(ps, lr, tape, dout, A, s, grads=None, math="fp32", overlap=Tr
         grads = torch.empty(grad_floats(s), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     _lib.check(_lib.lib().lft_train_backward(_ptr_array(ps), len(ps), lr.data_ptr(), tape.data_ptr(), dout.data_ptr(), grads.data_ptr(),
-                                             B, A, h, w, s, MATH[math], stream, None),
+                                             B, A, h, w, s, MATH[math], stream),
                "lft_train_backward")
     return grads
+
+
+def block_backward(ps, lr, tape, block, layer, d_out, A, s, grads, math="fp32"):
+    """lft_train_block_backward: the backward pass of ONE block (include/lft_hip.h: LFT_BLOCK_*) against the tape of a full forward;
+    returns the block's outgoing gradient [B, A*A, h, w, 64] (None for the feature extractor) and writes the block's parameter
+    gradients into the flat buffer `grads`."""
+    B, _, H, W = lr.shape
+    h, w = H // A, W // A
+    dev = lr.device
+    d_in = None if block == _lib.BLOCK_INIT else torch.empty((B, A * A, h, w, 64), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(_lib.lib().lft_train_block_backward(_ptr_array(ps), len(ps), lr.data_ptr(), tape.data_ptr(), block, layer, d_out.data_ptr(),
+                                                   None if d_in is None else d_in.data_ptr(), grads.data_ptr(), B, A, h, w, s, MATH[math], stream),
+               "lft_train_block_backward")
+    return d_in
 
 
 def grad_bucket(s: int, bucket: int):
@@ -94,7 +113,7 @@ def grad_bucket(s: int, bucket: int):
     return first.value, count.value
 
 
-def train_backward_buckets(ps, lr, tape, dout, A, s, grads, on_bucket, math="fp32", overlap=True):
+def train_backward_buckets(ps, lr, tape, dout, A, s, grads, on_bucket, math="fp32"):
     """lft_train_backward_buckets: the backward pass, calling on_bucket(bucket, first_float, n_floats) on the host each
     time a contiguous range of the flat gradient buffer is final (its last kernel enqueued on the current stream).
     An exception raised by on_bucket stops the pass at that boundary (the C call enqueues nothing further and returns
@@ -115,7 +134,7 @@ def train_backward_buckets(ps, lr, tape, dout, A, s, grads, on_bucket, math="fp3
 
     cb = _lib.BUCKET_FN(trampoline)
     rc = _lib.lib().lft_train_backward_buckets(_ptr_array(ps), len(ps), lr.data_ptr(), tape.data_ptr(), dout.data_ptr(), grads.data_ptr(),
-                                               B, A, h, w, s, MATH[math], stream, None,
+                                               B, A, h, w, s, MATH[math], stream,
                                                ctypes.cast(cb, ctypes.c_void_p), None)
     if err:
         raise err[0]
@@ -232,7 +251,7 @@ class TrainStep:
             torch.cuda.synchronize(dev)
             if not bucketed:
                 g["graphs"] = [torch.cuda.CUDAGraph()]
-                with torch.cuda.graph(g["graphs"][0]):
+                with torch.cuda.graph(g["graphs"][0], capture_error_mode=CAPTURE_MODE):
                     g["out"] = self._fwd_loss_bwd(g["lr"], g["hr"], g["tape"], g["dout"], self._scratch[1024:1025])
             else:
                 graphs = [torch.cuda.CUDAGraph() for _ in range(_lib.GRAD_BUCKETS)]
@@ -243,10 +262,10 @@ class TrainStep:
                     graphs[bucket].capture_end()
                     state["open"] = bucket + 1
                     if bucket + 1 < len(graphs):
-                        graphs[bucket + 1].capture_begin(pool=graphs[0].pool())
+                        graphs[bucket + 1].capture_begin(pool=graphs[0].pool(), capture_error_mode=CAPTURE_MODE)
 
                 with torch.cuda.stream(side):
-                    graphs[0].capture_begin()
+                    graphs[0].capture_begin(capture_error_mode=CAPTURE_MODE)
                     try:
                         g["out"] = self._fwd_loss_bwd(g["lr"], g["hr"], g["tape"], g["dout"], self._scratch[1024:1025], on_bucket=boundary)
                     except BaseException as e:

@@ -53,12 +53,16 @@ def test_no_cpu_fallback():
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "lft_hip.h")).read()
     declared = set(re.findall(r"^(?:int|const char\*)\s+(lft_\w+)\s*\(", hdr, flags=re.M))
+    test_hdr = open(os.path.join(ROOT, "include", "lft_hip_test.h")).read()
+    test_only = set(re.findall(r"^(?:int|const char\*)\s+(lft_\w+)\s*\(", test_hdr, flags=re.M))
+    assert test_only == set(_lib.TEST_EXPORTS) and not (test_only & declared)       # debug aids live in the test-only header
+    declared |= test_only
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     _lib.build()
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.lib().lft_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib().lft_version() == _lib.ABI_VERSION == 5
 
 
 def test_stale_library_and_changed_flags_are_noticed(monkeypatch):
@@ -114,7 +118,8 @@ def test_training_and_metrics_size_queries_and_argument_errors():
     assert b"78" in L.lft_last_error()
     assert L.lft_train_forward(arr, 78, 1, 1, 1, 1, 5, 8, 8, 2, 9, None) == -1
     assert b"math" in L.lft_last_error()
-    assert L.lft_train_backward(arr, 78, 1, 1, None, 1, 1, 5, 8, 8, 2, 0, None, None) == -1    # null dout
+    assert L.lft_train_backward(arr, 78, 1, 1, None, 1, 1, 5, 8, 8, 2, 0, None) == -1    # null dout
+    assert L.lft_train_block_backward(arr, 78, 1, 1, 9, 0, 1, 1, 1, 1, 5, 8, 8, 2, 0, None) == -1    # unknown block
     assert L.lft_view_metrics_scratch_bytes(1, 5, 32, 32, ctypes.byref(n)) == 0 and n.value == 25 * 4 * 3 * 8
     assert L.lft_view_metrics(1, 1, 1, 5, 8, 8, 2.0, 1, 1, 1, None) == -2                 # views smaller than the SSIM window
     assert L.lft_adam_step(1, 1, 1, 1, 10, 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, 0.0, None) == -1   # steps count from 1

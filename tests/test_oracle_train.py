@@ -91,6 +91,14 @@ def test_oracle_branches_and_gradients_on_unscreened_inputs(seed, golden_dir):
     finally:
         O.branch_masks = None
     assert abs(float(loss) - float(g["losses"][0])) <= 2e-6
+    # the loss's own kink: sign(sr - hr) agrees with the reference at every pixel that is not listed as near-zero
+    import hashlib
+    with torch.no_grad():
+        dd = (O.forward(sd, lr, A, s) - hr).numpy().ravel()
+    bits = dd > 0
+    bits[g["l1_near_idx"].astype(np.int64)] = False
+    assert hashlib.sha256(np.packbits(bits).tobytes()).digest() == g["l1_sha256"].tobytes()
+    assert float(np.abs(g["l1_near_d"]).max()) < 5e-4 and abs(float(np.abs(g["l1_near_d"]).min()) - float(g["l1_min_abs_diff"])) < 1e-9
     worst = 0.0
     for k, gr in grads.items():
         mine = gr.contiguous().numpy().ravel()
