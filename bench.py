@@ -145,7 +145,8 @@ def cpu_baseline(seconds: float, lr=None):
             "sample": f"{n} single-patch forwards (A{A}, {S}x, {H}x{W} LR, fp32, torch {torch.__version__} CPU ops) in {dt:.1f} s"}, ref
 
 
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+PROFILE_TAG = "r04"                    # the round whose committed PMC passes carry the hash of the sources being timed
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_hbm_traffic.json")
 
 
 def source_hash() -> str:
@@ -168,8 +169,8 @@ def traffic_from_profile(kernel: str, args) -> dict:
         prof = json.load(open(TRAFFIC_PROFILE))
         k = prof["kernels"].get(kernel)
         if k and prof.get("source_hash") == cur:
-            return {"traffic": k["total"], "traffic_source": "profiles/r03_hbm_traffic.json", "source_hash": cur}
-        return {"traffic": None, "traffic_note": "profiles/r03_hbm_traffic.json was taken on other sources (hash %s)" % prof.get("source_hash"),
+            return {"traffic": k["total"], "traffic_source": os.path.relpath(TRAFFIC_PROFILE, ROOT), "source_hash": cur}
+        return {"traffic": None, "traffic_note": "%s was taken on other sources (hash %s)" % (os.path.relpath(TRAFFIC_PROFILE, ROOT), prof.get("source_hash")),
                 "source_hash": cur}
     return {"traffic": None, "source_hash": cur}
 
@@ -201,7 +202,7 @@ def make_step(net, lr, args, inflight: int):
     return g, g
 
 
-SETTLE_SECONDS = 1.0      # untimed load in front of --warmup, see timed_protocol
+SETTLE_SECONDS = 3.0      # untimed load in front of --warmup, see timed_protocol
 SETTLE_MIN_STEPS = 100
 
 
@@ -219,11 +220,14 @@ def settle(step, lr, seconds=SETTLE_SECONDS):
 def timed_protocol(step, lr, args, sync):
     """THE timing protocol, shared by the headline, the parity paths and the latency path: SETTLE_SECONDS of untimed load, --warmup
     untimed steps, then exactly --steps steps bracketed by barrier + device synchronisation.
-    The settle time is chosen A PRIORI, not by which value reads best (round-3 advice): the card's power management has two time
-    constants -- clocks come up within tens of milliseconds of load and, on some boxes, are taken down again after ~0.4 s of it
-    (round 3, gpurun_out/r4k: a 20-step window read 8 640 - 9 000 patches/s behind 30 settle steps, 9 140 - 9 510 behind 100,
-    8 670 - 8 820 behind 1 000).  One second of load is past both, so a short timed window (the driver's --steps 20) measures the
-    SUSTAINED rate; the burst figure of the round-3 protocol (100 settle steps) is reported separately as `burst_path`."""
+    The settle time is chosen A PRIORI, not by which value reads best (round-3 advice): the card's power management has several time
+    constants -- clocks come up within tens of milliseconds of load; on some boxes they are taken down again after ~0.4 s of it (round 3,
+    gpurun_out/r4k: a 20-step window read 8 640 - 9 000 patches/s behind 30 settle steps, 9 140 - 9 510 behind 100, 8 670 - 8 820 behind
+    1 000); on others the rate keeps RISING for more than a second (round 4, gpurun_out/r4k: 9 390 behind 1 s of load, 9 780 in the
+    regions timed a few seconds later in the same process).  Three seconds of load is past all of them, so a short timed window (the
+    driver's --steps 20) measures the SUSTAINED rate; `sustained_path` (> 1 s timed) cross-checks it and `burst_path` is the round-3
+    protocol (100 settle steps from idle).
+    """
     with torch.no_grad():
         settle(step, lr)
         for _ in range(args.warmup):
@@ -378,7 +382,7 @@ def train_object(dev, math: str, with_roofline: bool = False):
             # HBM bytes per step of the family from the committed PMC passes of the training step (tools/collect_train_traffic.py),
             # only for the sources and the math mode they were taken on
             roof["traffic"] = None
-            tp = os.path.join(ROOT, "profiles", f"r03_train_hbm_traffic_{math}.json")
+            tp = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_train_hbm_traffic_{math}.json")
             if os.path.exists(tp):
                 prof = json.load(open(tp))
                 if prof.get("source_hash") == source_hash() and dom in prof["kernels"]:

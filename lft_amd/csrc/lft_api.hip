@@ -246,7 +246,10 @@ template <typename T> bool tok_lane_major(const Dims& d) {
 template <typename T, bool PE_ONLY>
 int launch_spa1(unsigned nwg, const T* in, const T* ws, const float* ln, const T* petok, T* tok, T* q, T* k, T* v, T* pe_out,
                 int nimg, const Dims& d, hipStream_t st, unsigned* status) {
-    const size_t l16 = lds_spa1<T, 16>(d.w), l8 = lds_spa1<T, 8>(d.w);
+#ifndef LFT_SPA1_EXTRA_LDS
+#define LFT_SPA1_EXTRA_LDS 0
+#endif
+    const size_t l16 = lds_spa1<T, 16>(d.w) + LFT_SPA1_EXTRA_LDS, l8 = lds_spa1<T, 8>(d.w) + LFT_SPA1_EXTRA_LDS;
     const size_t share = kMaxLds / LFT_SPA_OCC;                           // LDS per workgroup if LFT_SPA_OCC of them share a CU
     const bool use8 = (l16 > share && l8 <= share) || l16 > kMaxLds;
     int rc;
@@ -430,7 +433,10 @@ int spa_part_b(const void* packed, const PackedLayout& L, int l, const T* skip, 
     if constexpr (sizeof(T) == 2) {
         // bf16: windowed attention + out_proj + FFN + 1x1x1 conv in ONE kernel (the attention output stays in registers)
         const unsigned ntile = (unsigned)(nimg * ((d.h + kAttTY - 1) / kAttTY) * ((d.w + kAttTX - 1) / kAttTX));
-        const size_t lds = kSpaBLds;
+#ifndef LFT_SPAB_EXTRA_LDS
+#define LFT_SPAB_EXTRA_LDS 0                 // experiments: pad the request so that fewer workgroups share a CU
+#endif
+        const size_t lds = kSpaBLds + LFT_SPAB_EXTRA_LDS;
 #define LFT_LAUNCH_SPAB(SKV, LMV, YLV)                                                                                      \
     do {                                                                                                                    \
         if ((rc = allow_lds(k_spa_b<T, SKV, LMV, YLV>, lds, "k_spa_b"))) return rc;                                            \

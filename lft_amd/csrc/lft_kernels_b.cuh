@@ -447,6 +447,9 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
         // tools/asm_load_hazards.py reports 57 reads of in-flight registers for this variant.  The block therefore stays behind Q.
         setup_tiles();
 #endif
+        // (No LFT_STAMP between here and the last Wq wait: a stamp is compiler-visible code with live registers of its own -- in the
+        // diagnostic build it made hipcc spill and MOVE asm-loaded registers that were still in flight, and the kernel faulted on a
+        // garbage address.  Run tools/asm_load_hazards.py on a diagnostic listing before launching it.)
         // in flight: 2 + 16 + 16 + 18 = 52.  Tokens, position tokens and LayerNorm parameters first:
         wait_vm_8<16 + 2 * kAdPerWave>(tokr);
         wait_vm_8<16 + 2 * kAdPerWave>(per);
@@ -461,6 +464,9 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
 #pragma unroll
             for (int j = 0; j < 8; ++j) n[kidx >> 1][8 * (kidx & 1) + j] = (float)vt[j] + (float)vp[j];
         }
+        // (Round 4 tried a third fragment set in the dead position-token registers, requested here so that head pair 2's Wq arrives
+        // under the LayerNorm instead of costing an L2 round trip in front of Q2: 32 more live registers across the LayerNorm -> 148 B
+        // of scratch and asm-loaded registers moved while in flight (tools/asm_load_hazards.py: 280 reads).  Not adopted.)
         layernorm_acc<4, true>(n, lds_ln + 256, lds_ln + 256 + 128, hh, bad);
         Frag<T> nf[8];
         acc_frags<4, T>(n, nf);

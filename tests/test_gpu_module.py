@@ -42,7 +42,8 @@ def test_forward_matches_reference_fixture(name, precision, golden_dir):
     print(f"{name} [{precision}] rel max err {rel:.3e}  element-wise rel err on |ref|>=0.05: max {float(ew.max()):.3e} mean {float(ew.mean()):.3e} "
           f"({int(m.sum())} px)  psnr(ours, reference) {O.psnr(out, ref):.2f} dB")
     assert out.shape == ref.shape
-    assert float(ew.max()) <= {"fp32": 1e-4, "fp16": 2e-2, "bf16": 5e-2}[precision]
+    # element-wise gates at the observed level (round 4, seven fixtures: fp32 5.6e-6, fp16 3.6e-3, bf16 3.2e-2 at the worst pixel)
+    assert float(ew.max()) <= {"fp32": 2e-5, "fp16": 6e-3, "bf16": 4.5e-2}[precision]
     # north_star: 1e-3 relative -- met by the fp32 path (observed 3e-7) and by the fp16 path (11 significant bits, ~2e-4).  The bf16
     # path rounds every MFMA operand and every inter-kernel tensor to 8 significant bits: 1.5e-3 .. 1.9e-3 observed, which does NOT
     # meet 1e-3; its gate only pins that level.
