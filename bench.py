@@ -206,8 +206,9 @@ SETTLE_SECONDS = 3.0      # untimed load in front of --warmup, see timed_protoco
 SETTLE_MIN_STEPS = 100
 
 
-def settle(step, lr, seconds=SETTLE_SECONDS):
+def settle(step, lr, seconds=None):
     """Run the step under load for `seconds` (and at least SETTLE_MIN_STEPS steps); returns the number of steps it took."""
+    seconds = SETTLE_SECONDS if seconds is None else seconds
     n, t0 = 0, time.perf_counter()
     while n < SETTLE_MIN_STEPS or time.perf_counter() - t0 < seconds:
         for _ in range(50):
@@ -540,7 +541,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the parity_path, latency_path and train objects (A/B timing runs)")
+    ap.add_argument("--settle-seconds", type=float, default=None, help="untimed load in front of --warmup (default SETTLE_SECONDS; profiling passes under counters use a short one)")
     args = ap.parse_args()
+    global SETTLE_SECONDS
+    if args.settle_seconds is not None:
+        SETTLE_SECONDS = args.settle_seconds
     kind, c_ang, c_scale, c_lr, c_batch, c_prec = CONFIGS[args.config]
     args.ang = args.ang or c_ang
     args.scale = args.scale or c_scale
