@@ -509,7 +509,7 @@ def run_training(args, rank, world, dev, dist, rehearsal):
            "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
            "per_rank_ms": ranks_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            **({"rehearsal": f"{world} ranks share one GPU over gloo: not a scaling measurement"} if rehearsal else {}),
-           "dtype": "f32" if math == "fp32" else "f32 (split-bf16 products)", "data": "synthetic",
+           "dtype": {"fp32": "f32", "bf16x3": "f32 (split-bf16 products)", "bf16x6": "f32 (weight gradients: six bf16 products, fp32-class)"}[math], "data": "synthetic",
            "config": {"workload": f"LFT {A}x{A} angRes {S}xSR training step (Adam, bucketed gradient all-reduce), batch={B} per GPU, {H}x{W} LR patches",
                       "name": args.config, "global_batch": world * B, "parallelism": f"dp{world} (flat gradient buffer summed in 3 buckets under the backward pass)",
                       "hip_graph": not args.no_graph, "algorithmic_gflop_per_patch_step": 3 * flops_fwd / 1e9},
@@ -537,7 +537,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="HIP streams ONE step's batch is split over (1 = whole-batch kernels; overlap then comes from --inflight)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host each step instead of replaying a HIP graph")
     ap.add_argument("--inflight", type=int, default=2, help="steps in flight: captured forwards replayed round-robin on this many streams (1 = strictly one after the other)")
-    ap.add_argument("--train-math", default="fp32", choices=["fp32", "bf16x3"], help="cfg3: GEMM arithmetic of the training kernels")
+    ap.add_argument("--train-math", default="fp32", choices=["fp32", "bf16x3", "bf16x6"], help="cfg3: GEMM arithmetic of the training kernels")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the parity_path, latency_path and train objects (A/B timing runs)")
@@ -713,6 +713,7 @@ def main():
             result["train"] = train_object(dev, "fp32", with_roofline=True)
             result["train"]["bf16x3"] = {k: v for k, v in train_object(dev, "bf16x3", with_roofline=True).items()
                                           if k in ("ms_per_step", "patches_per_s", "algorithmic_tflops", "roofline")}
+            result["train"]["bf16x6"] = {k: v for k, v in train_object(dev, "bf16x6").items() if k in ("ms_per_step", "patches_per_s", "algorithmic_tflops")}
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle on host cores ...")
             result["cpu_baseline"], ref = cpu_baseline(args.cpu_seconds, lr[:1].cpu())

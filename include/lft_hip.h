@@ -43,6 +43,8 @@ extern "C" {
  * use the same mode (the packed weights in the tape are in the mode's format). */
 #define LFT_MATH_F32 0
 #define LFT_MATH_BF16X3 1
+#define LFT_MATH_BF16X6 2   /* fp32 operands as THREE bf16 numbers (x = a + b + c exactly), six bf16 MFMAs per product (the three smallest of the
+                             * nine terms dropped: <= 2^-23 relative, fp32-class) at 6/16 of the fp32-MFMA cost; every GEMM of the step */
 
 #define LFT_ERR_ARG (-1)         /* null pointer / bad enum */
 #define LFT_ERR_SHAPE (-2)       /* shape outside what this build supports */

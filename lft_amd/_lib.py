@@ -18,7 +18,7 @@ ABI_VERSION = 5                      # LFT_ABI_VERSION of include/lft_hip.h: lib
 STATUS_NONFINITE = 1001              # LFT_STATUS_NONFINITE
 
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
-MATH_F32, MATH_BF16X3 = 0, 1
+MATH_F32, MATH_BF16X3, MATH_BF16X6 = 0, 1, 2
 NUM_PARAMS = 78
 
 _lib = None

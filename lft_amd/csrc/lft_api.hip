@@ -870,7 +870,7 @@ int lft_train_forward(const float* const* params, int nparams, const float* lr, 
     if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
     for (int i = 0; i < nparams; ++i) if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
-    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32 or LFT_MATH_BF16X3, got %d", math);
+    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3 && math != LFT_MATH_BF16X6) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32, LFT_MATH_BF16X3 or LFT_MATH_BF16X6, got %d", math);
     return train_forward(params, lr, out, static_cast<float*>(tape), d, math, static_cast<hipStream_t>(stream));
 }
 int lft_train_backward(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
@@ -880,7 +880,7 @@ int lft_train_backward(const float* const* params, int nparams, const float* lr,
     if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
     for (int i = 0; i < nparams; ++i) if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
-    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32 or LFT_MATH_BF16X3, got %d", math);
+    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3 && math != LFT_MATH_BF16X6) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32, LFT_MATH_BF16X3 or LFT_MATH_BF16X6, got %d", math);
     return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, math, static_cast<hipStream_t>(stream));
 }
 int lft_train_backward_buckets(const float* const* params, int nparams, const float* lr, void* tape, const float* dout, float* grads,
@@ -891,7 +891,7 @@ int lft_train_backward_buckets(const float* const* params, int nparams, const fl
     if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
     for (int i = 0; i < nparams; ++i) if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
-    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32 or LFT_MATH_BF16X3, got %d", math);
+    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3 && math != LFT_MATH_BF16X6) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32, LFT_MATH_BF16X3 or LFT_MATH_BF16X6, got %d", math);
     return train_backward(params, lr, static_cast<float*>(tape), dout, grads, d, math, static_cast<hipStream_t>(stream), on_bucket, user);
 }
 int lft_train_block_backward(const float* const* params, int nparams, const float* lr, void* tape, int block, int layer,
@@ -905,7 +905,7 @@ int lft_train_block_backward(const float* const* params, int nparams, const floa
     if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
     for (int i = 0; i < nparams; ++i) if (!params[i]) return fail(LFT_ERR_ARG, "parameter %d is null", i);
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
-    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32 or LFT_MATH_BF16X3, got %d", math);
+    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3 && math != LFT_MATH_BF16X6) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32, LFT_MATH_BF16X3 or LFT_MATH_BF16X6, got %d", math);
     const BlockSel sel{block, layer, d_out, d_in};
     return train_backward(params, lr, static_cast<float*>(tape), block == LFT_BLOCK_UPSAMPLE ? d_out : nullptr, grads, d, math,
                           static_cast<hipStream_t>(stream), nullptr, nullptr, false, nullptr, nullptr, &sel);
@@ -916,7 +916,7 @@ int lft_train_step_profiled(const float* const* params, int nparams, const float
     if (!params || !lr || !out || !tape || !dout || !grads || !ms_out || !names_out || !n_out) return fail(LFT_ERR_ARG, "null pointer");
     if (nparams != LFT_NUM_PARAMS) return fail(LFT_ERR_ARG, "expected %d parameter tensors, got %d", LFT_NUM_PARAMS, nparams);
     if ((rc = make_dims(B, A, h, w, s, LFT_PREC_F32, &d))) return rc;
-    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32 or LFT_MATH_BF16X3, got %d", math);
+    if (math != LFT_MATH_F32 && math != LFT_MATH_BF16X3 && math != LFT_MATH_BF16X6) return fail(LFT_ERR_ARG, "math must be LFT_MATH_F32, LFT_MATH_BF16X3 or LFT_MATH_BF16X6, got %d", math);
     hipStream_t st = static_cast<hipStream_t>(stream);
     g_prof.on = true; g_prof.st = st; g_prof.ev.clear(); g_prof.names.clear();
     prof_mark("start");

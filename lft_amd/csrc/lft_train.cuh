@@ -38,6 +38,37 @@ LFT_DEV void mma3(const Frag2& a, const Frag2& b, f32x16& c) {
     mma(a.hi, b.lo, c);
     mma(a.hi, b.hi, c);
 }
+// "bf16x6" (round 4): an fp32 number IS the sum of three bf16 numbers, x = a + b + c exactly (8 + 8 + 8 significant bits; each
+// remainder is exact in fp32), so a product is the sum of nine bf16 products of which the three smallest (b c', c b', c c':
+// <= 2^-23 |x y| together) are dropped:
+//   x * y ~= a a' + (a b' + b a') + (a c' + c a' + b b')        6 MFMAs, fp32 accumulate, smallest terms first
+// -- fp32-class products (the fp32 MFMA rounds its product to 2^-24) at 6/16 of the fp32-MFMA cost.  Used by the weight-gradient
+// kernel, whose operands are activations split in registers (no packed weights, no layout change).
+struct Frag3 { Frag<bf16_t> a, b, c; };
+LFT_DEV void split3(float x, bf16_t& a, bf16_t& b, bf16_t& c) {
+    a = (bf16_t)x;
+    const float r1 = x - (float)a;
+    b = (bf16_t)r1;
+    c = (bf16_t)(r1 - (float)b);
+}
+LFT_DEV Frag3 split3_frag(const Frag<float>& f) {
+    Frag3 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bf16_t a, b, c;
+        split3(j < 4 ? f.lo[j] : f.hi[j - 4], a, b, c);
+        r.a.v[j] = a; r.b.v[j] = b; r.c.v[j] = c;
+    }
+    return r;
+}
+LFT_DEV void mma6(const Frag3& x, const Frag3& y, f32x16& c) {
+    mma(x.c, y.a, c);
+    mma(x.a, y.c, c);
+    mma(x.b, y.b, c);
+    mma(x.b, y.a, c);
+    mma(x.a, y.b, c);
+    mma(x.a, y.a, c);
+}
 LFT_DEV Frag2 load_wfrag2(const float* __restrict__ stream, int f, int lane) {
     const char* base = reinterpret_cast<const char*>(stream) + (size_t)f * 2048 + lane * 16;
     Frag2 r;
@@ -45,7 +76,19 @@ LFT_DEV Frag2 load_wfrag2(const float* __restrict__ stream, int f, int lane) {
     r.lo.v = __builtin_bit_cast(bf16x8, load_raw16(base + 1024));
     return r;
 }
-// k_pack's twin for the split mode: same PackOp description (natural k order), writes hi / lo pieces.
+// bf16x6: packed weight fragment f = [1 KiB a][1 KiB b][1 KiB c] (3 KiB; the fp32 and split-bf16 fragments are 2 KiB)
+constexpr int kFragBytes2 = 2048, kFragBytes3 = 3072;
+LFT_DEV Frag3 load_wfrag3(const float* __restrict__ stream, int f, int lane) {
+    const char* base = reinterpret_cast<const char*>(stream) + (size_t)f * kFragBytes3 + lane * 16;
+    Frag3 r;
+    r.a.v = __builtin_bit_cast(bf16x8, load_raw16(base));
+    r.b.v = __builtin_bit_cast(bf16x8, load_raw16(base + 1024));
+    r.c.v = __builtin_bit_cast(bf16x8, load_raw16(base + 2048));
+    return r;
+}
+// k_pack's twin for the split modes: same PackOp description (natural k order), writes hi / lo pieces (THREE = false) or the
+// three exact bf16 parts a / b / c (THREE = true, 3 KiB per fragment).
+template <bool THREE>
 __global__ __launch_bounds__(64) void k_pack_split(PackArgs args, float* __restrict__ dst) {
     const int f = blockIdx.x, lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     int oi = 0;
@@ -55,7 +98,7 @@ __global__ __launch_bounds__(64) void k_pack_split(PackArgs args, float* __restr
     int nt, ks;
     wfrag_coords(op.ntiles, op.ksteps, f - op.frag0, op.order, nt, ks);
     const int n = 32 * nt + r;
-    bf16_t* d = reinterpret_cast<bf16_t*>(dst) + (size_t)f * 1024;                 // 2 KiB = 1024 bf16 per fragment
+    bf16_t* d = reinterpret_cast<bf16_t*>(dst) + (size_t)f * (THREE ? 1536 : 1024);   // 2 KiB = 1024 bf16 (3 KiB = 1536) per fragment
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int kk = op.k0 + 16 * ks + 8 * h + j;
@@ -65,9 +108,15 @@ __global__ __launch_bounds__(64) void k_pack_split(PackArgs args, float* __restr
             else if (op.kind == 1) v = upm_entry(op.src, n, kk, op.s);
             else v = kk < (op.s + 2) * (op.s + 2) ? upm_entry(op.src, kk, n, op.s) : 0.0f;
         }
-        const bf16_t hi = (bf16_t)v;
-        d[lane * 8 + j] = hi;
-        d[512 + lane * 8 + j] = (bf16_t)(v - (float)hi);
+        if constexpr (THREE) {
+            bf16_t a, b, c;
+            split3(v, a, b, c);
+            d[lane * 8 + j] = a; d[512 + lane * 8 + j] = b; d[1024 + lane * 8 + j] = c;
+        } else {
+            const bf16_t hi = (bf16_t)v;
+            d[lane * 8 + j] = hi;
+            d[512 + lane * 8 + j] = (bf16_t)(v - (float)hi);
+        }
     }
 }
 
@@ -94,8 +143,9 @@ struct LinP {
 // TILED (plain Linears at small batch): the 32 input rows of a wave, consecutive in memory, are fetched in coalesced
 // 64-channel chunks through the scratch instead of one 32-byte piece per lane and k-step -- fewer, fuller memory
 // requests when there are too few waves to hide latency; at large batch the direct form's higher occupancy wins.
-template <int NT, bool M3, bool TILED>
+template <int NT, int MM, bool TILED>      // MM: 0 exact fp32 MFMA, 1 split-bf16 (3 products), 2 bf16x6 (6 products, fp32-class)
 __global__ __launch_bounds__(256, 3) void k_lin(const LinP p) {
+    constexpr bool M3 = MM == 1;
     constexpr int SCR = TileIO<(NT > 2 ? NT : 2), float>::BYTES;          // output tile or a 64-channel input chunk
     __shared__ __attribute__((aligned(16))) char scr_all[4 * SCR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, kh = lane >> 5;
@@ -117,7 +167,11 @@ __global__ __launch_bounds__(256, 3) void k_lin(const LinP p) {
             load_tile_frags_s<4, float>(p.X + t0 * p.ldx + 16 * k0, (size_t)p.ldx * 4, nvalid, lane, b, scr);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                if constexpr (M3) {
+                if constexpr (MM == 2) {
+                    const Frag3 b3 = split3_frag(b[ks]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mma6(load_wfrag3(p.Wp, wfrag_index(p.OT, p.KS, ot0 + nt, k0 + ks), lane), b3, acc[nt]);
+                } else if constexpr (M3) {
                     const Frag2 b2 = split_frag(b[ks]);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) mma3(load_wfrag2(p.Wp, wfrag_index(p.OT, p.KS, ot0 + nt, k0 + ks), lane), b2, acc[nt]);
@@ -136,7 +190,11 @@ __global__ __launch_bounds__(256, 3) void k_lin(const LinP p) {
         const int fbase = tap * p.OT * p.KS;
         for (int ks = 0; ks < p.KS; ++ks) {
             const Frag<float> b = load_row8(row + 16 * ks, ok, 0.0f);
-            if constexpr (M3) {
+            if constexpr (MM == 2) {
+                const Frag3 b3 = split3_frag(b);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mma6(load_wfrag3(p.Wp, fbase + wfrag_index(p.OT, p.KS, ot0 + nt, ks), lane), b3, acc[nt]);
+            } else if constexpr (M3) {
                 const Frag2 b2 = split_frag(b);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) mma3(load_wfrag2(p.Wp, fbase + wfrag_index(p.OT, p.KS, ot0 + nt, ks), lane), b2, acc[nt]);
@@ -203,9 +261,14 @@ template <int DIR> LFT_DEV f32x4 lane_shift1(f32x4 v, bool edge) { return __buil
 // registers one lane over (lane_shift1), the image's left / right border is the shift's zero.  Input rows come from L2 three
 // times instead of nine and the split into bf16 pairs is done once per row fragment instead of once per tap -- in the SAME step
 // order (tap row, tap column, k-step) and with the same operand values as the generic form, so the results are bit-identical.
-template <int NT, bool M3, int KS3 = 0>
+template <int NT, int MM, int KS3 = 0>     // MM as k_lin
 __global__ __launch_bounds__(256, 3) void k_linr(const LinP p) {
-    constexpr int CHUNK = NT * 2048, PPW = NT / 2;                        // bytes of weights per k-step; 1 KiB pieces per wave and chunk
+    constexpr bool M3 = MM == 1;
+    constexpr int FB = MM == 2 ? kFragBytes3 : kFragBytes2;               // bytes per packed fragment
+    constexpr int CHUNK = NT * FB, NPIECE = CHUNK / 1024;                 // bytes / 1 KiB pieces of weights per k-step
+    // pieces per wave and chunk: NPIECE / 4, except bf16x6 with two output tiles (6 pieces): waves 0, 1 move two, waves 2, 3 one
+    constexpr bool EVEN = NPIECE % 4 == 0;
+    constexpr int PPW = EVEN ? NPIECE / 4 : 2;
     constexpr int SCR = TileIO<NT, float>::BYTES;
     static_assert(NT == 2 || NT == 4, "two or four output tiles");
     __shared__ __attribute__((aligned(16))) char lds[2 * CHUNK + (4 * SCR > CHUNK ? 4 * SCR : CHUNK)];
@@ -230,11 +293,13 @@ __global__ __launch_bounds__(256, 3) void k_linr(const LinP p) {
     // the ring: chunk c (the NT fragments of k-step c) in slot c % 3; every wave moves PPW pieces of it.  The DMA is issued from
     // inline asm: hipcc does not know it, so its waits for the row loads are computed without it (stricter, never unsafe) and
     // it does not guard the ring's LDS reads with a vmcnt(0) of its own (it did, with the builtin form)
-    const char* wsrc = reinterpret_cast<const char*>(p.Wp) + (size_t)wfrag_index(p.OT, p.KS, ot0, 0) * 2048 + (wave * PPW) * 1024 + lane * 16;
+    const int my_first = EVEN ? wave * PPW : (wave < 2 ? 2 * wave : 2 + wave), my_count = EVEN ? PPW : (wave < 2 ? 2 : 1);   // wave-uniform
+    const char* wsrc = reinterpret_cast<const char*>(p.Wp) + (size_t)wfrag_index(p.OT, p.KS, ot0, 0) * FB + my_first * 1024 + lane * 16;
     auto issue_w = [&](int c, int slot) {
         if (c >= S) return;
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) glds16_asm(wsrc + (size_t)c * CHUNK + i * 1024, lds + slot * CHUNK + (wave * PPW + i) * 1024);
+        for (int i = 0; i < PPW; ++i)
+            if (EVEN || i < my_count) glds16_asm(wsrc + (size_t)c * CHUNK + i * 1024, lds + slot * CHUNK + (my_first + i) * 1024);
     };
     issue_w(0, 0);
     issue_w(1, 1);
@@ -251,12 +316,13 @@ __global__ __launch_bounds__(256, 3) void k_linr(const LinP p) {
             Frag<float> xr[KS3];
 #pragma unroll
             for (int ks = 0; ks < KS3; ++ks) xr[ks] = load_row8(row + 16 * ks, true, 0.0f);
-            Frag<float> xf[M3 ? 1 : KS3];
+            Frag<float> xf[MM == 0 ? KS3 : 1];
             Frag2 x2[M3 ? KS3 : 1];
+            Frag3 x3[MM == 2 ? KS3 : 1];
 #pragma unroll
             for (int ks = 0; ks < KS3; ++ks) {
                 const Frag<float> z = okr ? xr[ks] : frag_zero(0.0f);
-                if constexpr (M3) x2[ks] = split_frag(z); else xf[ks] = z;
+                if constexpr (MM == 2) x3[ks] = split3_frag(z); else if constexpr (M3) x2[ks] = split_frag(z); else xf[ks] = z;
             }
             for (int dxi = 0; dxi < 3; ++dxi) {
                 const int dx = p.flip ? 1 - dxi : dxi - 1;               // uniform
@@ -264,13 +330,18 @@ __global__ __launch_bounds__(256, 3) void k_linr(const LinP p) {
                 for (int ks = 0; ks < KS3; ++ks) {
                     // this wave's pieces of chunk cs have landed (only those of chunk cs + 1 may still be in flight: the counted wait
                     // of WRing), then the barrier publishes the chunk and retires chunk cs - 1
-                    wait_vmcnt(cs + 1 < S ? PPW : 0);
+                    wait_vmcnt(cs + 1 < S ? my_count : 0);
                     wg_barrier_keep_vm();
                     issue_w(cs + 2, slot == 0 ? 2 : slot - 1);
                     const char* base = lds + slot * CHUNK + lane * 16;
                     Frag2 b2;
+                    Frag3 b3;
                     Frag<float> b;
-                    if constexpr (M3) {
+                    if constexpr (MM == 2) {
+                        b3 = x3[ks];
+                        if (dx > 0) { b3.a.v = lane_shift1<1>(x3[ks].a.v, e_hi); b3.b.v = lane_shift1<1>(x3[ks].b.v, e_hi); b3.c.v = lane_shift1<1>(x3[ks].c.v, e_hi); }
+                        else if (dx < 0) { b3.a.v = lane_shift1<-1>(x3[ks].a.v, e_lo); b3.b.v = lane_shift1<-1>(x3[ks].b.v, e_lo); b3.c.v = lane_shift1<-1>(x3[ks].c.v, e_lo); }
+                    } else if constexpr (M3) {
                         b2 = x2[ks];
                         if (dx > 0) { b2.hi.v = lane_shift1<1>(x2[ks].hi.v, e_hi); b2.lo.v = lane_shift1<1>(x2[ks].lo.v, e_hi); }
                         else if (dx < 0) { b2.hi.v = lane_shift1<-1>(x2[ks].hi.v, e_lo); b2.lo.v = lane_shift1<-1>(x2[ks].lo.v, e_lo); }
@@ -281,7 +352,13 @@ __global__ __launch_bounds__(256, 3) void k_linr(const LinP p) {
                     }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        if constexpr (M3) {
+                        if constexpr (MM == 2) {
+                            Frag3 w3;
+                            w3.a.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * FB));
+                            w3.b.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * FB + 1024));
+                            w3.c.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * FB + 2048));
+                            mma6(w3, b3, acc[nt]);
+                        } else if constexpr (M3) {
                             Frag2 w2;
                             w2.hi.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * 2048));
                             w2.lo.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * 2048 + 1024));
@@ -313,7 +390,11 @@ __global__ __launch_bounds__(256, 3) void k_linr(const LinP p) {
     auto step = [&](const Frag<float>& xraw, bool ok) {
         const Frag<float> xs = ok ? xraw : frag_zero(0.0f);
         Frag2 b2;
-        if constexpr (M3) {
+        Frag3 b3;
+        if constexpr (MM == 2) {
+            b3 = split3_frag(xs);
+            asm volatile("" :: "v"(b3.a.v), "v"(b3.b.v), "v"(b3.c.v));
+        } else if constexpr (M3) {
             b2 = split_frag(xs);                                         // (the compiler's wait for the rows sits here, in front of the barrier)
             asm volatile("" :: "v"(b2.hi.v), "v"(b2.lo.v));
         } else {
@@ -324,7 +405,13 @@ __global__ __launch_bounds__(256, 3) void k_linr(const LinP p) {
         const char* base = lds + slot * CHUNK + lane * 16;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            if constexpr (M3) {
+            if constexpr (MM == 2) {
+                Frag3 w3;
+                w3.a.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * FB));
+                w3.b.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * FB + 1024));
+                w3.c.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * FB + 2048));
+                mma6(w3, b3, acc[nt]);
+            } else if constexpr (M3) {
                 Frag2 w2;
                 w2.hi.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * 2048));
                 w2.lo.v = __builtin_bit_cast(bf16x8, load_raw16(base + nt * 2048 + 1024));
@@ -393,8 +480,9 @@ struct WgP {
 // split) once for three products and the three shifted X rows are neighbours in memory.
 // The 4 waves of a workgroup split the chunk's tokens and add their accumulators through LDS, in a fixed order:
 // one partial image per workgroup (a quarter of the partial-sum traffic for the same number of waves in flight).
-template <int NI, bool M3, int TX>
+template <int NI, int MM, int TX>      // MM: 0 exact fp32 MFMA, 1 split-bf16 (3 products), 2 bf16x6 (6 products, fp32-class)
 __global__ __launch_bounds__(256, TX == 3 ? 2 : 3) void k_wgrad(const WgP p) {
+    constexpr bool M3 = MM == 1;
     extern __shared__ __attribute__((aligned(16))) float wred[];        // [3 waves][TX * NI tiles][16][64]
     const int lane = threadIdx.x & 63, r = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -458,7 +546,23 @@ __global__ __launch_bounds__(256, TX == 3 ? 2 : 3) void k_wgrad(const WgP p) {
                 vy += 16u * p.ldy * 4u; vx += 16u * p.ldx * 4u;
                 xb += 16;
                 if (xb == 32) { xb = 0; if (++yw == p.h) yw = 0; }
-                if constexpr (M3) {
+                if constexpr (MM == 2) {
+                    const Frag3 a3 = split3_frag(a);
+                    bf16_t sa[NI][10], sb[NI][10], sc[NI][10];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int e = 0; e < 10; ++e) split3(v[ni][e], sa[ni][e], sb[ni][e], sc[ni][e]);
+#pragma unroll
+                    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            Frag3 b3;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { b3.a.v[j] = sa[ni][j + tx]; b3.b.v[j] = sb[ni][j + tx]; b3.c.v[j] = sc[ni][j + tx]; }
+                            mma6(a3, b3, acc[tx][ni]);
+                        }
+                } else if constexpr (M3) {
                     const Frag2 a2 = split_frag(a);
                     bf16_t hi[NI][10], lo[NI][10];
 #pragma unroll
@@ -516,7 +620,13 @@ __global__ __launch_bounds__(256, TX == 3 ? 2 : 3) void k_wgrad(const WgP p) {
             xs += 16;
             while (xs >= p.w) { xs -= p.w; if (++ys == p.h) ys = 0; }
         }
-        if constexpr (M3) {
+        if constexpr (MM == 2) {
+            const Frag3 a3 = split3_frag(a);
+#pragma unroll
+            for (int tx = 0; tx < TX; ++tx)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) mma6(a3, split3_frag(b[tx][ni]), acc[tx][ni]);
+        } else if constexpr (M3) {
             const Frag2 a2 = split_frag(a);
 #pragma unroll
             for (int tx = 0; tx < TX; ++tx)

@@ -126,7 +126,7 @@ TrainLayout train_layout(const Dims& d) {
     size_t o = 0;
     auto take = [&](size_t floats) { size_t r = o; o += (floats + 63) & ~(size_t)63; return r; };
     const size_t n = (size_t)d.ntok, ss = (size_t)d.s * d.s;
-    T.wp = take(build_views(nullptr, d.s, nullptr).nfrags * 512);
+    T.wp = take(build_views(nullptr, d.s, nullptr).nfrags * 768);     // 3 KiB per fragment in the bf16x6 mode (2 KiB in the others)
     T.pe_ang = take((size_t)d.V * 64); T.pe_spa = take((size_t)d.hw * 64);
     T.x0 = take(n * 64); T.c1 = take(n * 64); T.c2 = take(n * 64); T.c3 = take(n * 64); T.feat = take(n * 64);
     for (int l = 0; l < kLayers; ++l) {
@@ -162,7 +162,7 @@ TrainLayout train_layout(const Dims& d) {
     return T;
 }
 
-int run_pack_split(std::vector<PackOp>& ops, float* dst, int expect_frags, hipStream_t st) {
+int run_pack_split(std::vector<PackOp>& ops, float* dst, int expect_frags, hipStream_t st, bool three = false) {
     int total = 0;
     size_t i = 0;
     while (i < ops.size()) {
@@ -174,7 +174,8 @@ int run_pack_split(std::vector<PackOp>& ops, float* dst, int expect_frags, hipSt
             nf += ops[i].ntiles * ops[i].ksteps;
             ++a.nops; ++i;
         }
-        k_pack_split<<<nf, 64, 0, st>>>(a, dst + (size_t)total * 512);
+        if (three) k_pack_split<true><<<nf, 64, 0, st>>>(a, dst + (size_t)total * 768);
+        else k_pack_split<false><<<nf, 64, 0, st>>>(a, dst + (size_t)total * 512);
         LFT_LAUNCH_OK("k_pack_split");
         total += nf;
     }
@@ -221,14 +222,14 @@ int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int l
     const WView& v = c.W.v[view];
     if (nOT <= 0) nOT = v.OT;
     if ((v.taps != 1 && (ot0 || nOT != v.OT))) return fail(LFT_ERR_ARG, "run_lin: bad tile block (view %d)", view);
-    LinP p{X, ldx, c.F(c.T.wp) + v.frag0 * 512, v.OT, v.KS, ot0, R, ldr, Y, ldy, M, ldy, mact, v.taps, flip, act, c.d.h, c.d.w, N, 1};
+    const int mm = c.math == LFT_MATH_BF16X3 ? 1 : c.math == LFT_MATH_BF16X6 ? 2 : 0;
+    LinP p{X, ldx, c.F(c.T.wp) + v.frag0 * (mm == 2 ? 768 : 512), v.OT, v.KS, ot0, R, ldr, Y, ldy, M, ldy, mact, v.taps, flip, act, c.d.h, c.d.w, N, 1};
     const unsigned gx = (unsigned)((N + 127) / 128);
     // output tiles per wave: 4 when that still gives the chip >= 2 waves per SIMD, fewer (more, thinner waves) for small N
     const long long tiles = (N + 31) / 32;
     int nt = 4;
     while (nt > 1 && (nOT % nt || tiles * (nOT / nt) < 2048)) nt >>= 1;
     const dim3 g(gx, (unsigned)(nOT / nt));
-    const bool m3 = c.math == LFT_MATH_BF16X3;
     // weights through the LDS ring (k_linr) when every workgroup's output block is one packed group of the view: full groups of
     // four tiles, or the view's last group of two; large N only (below, the coalesced-input form of k_lin is the faster one)
     const bool full4 = nt == 4 && ot0 % 4 == 0 && ot0 + nOT <= (v.OT / 4) * 4;
@@ -240,15 +241,16 @@ int run_lin(const TrainCtx& c, int view, int ot0, int nOT, const float* X, int l
     const bool tiled = v.taps == 1 && v.KS % 4 == 0 && N <= 65536;       // measured: +7 % at 25.6 k tokens, -4 % at 205 k
 #define LFT_LAUNCH_LIN(NTV)                                                                                          \
     do {                                                                                                             \
-        if (m3) { if (tiled) k_lin<NTV, true, true><<<g, 256, 0, c.st>>>(p); else k_lin<NTV, true, false><<<g, 256, 0, c.st>>>(p); }      \
-        else { if (tiled) k_lin<NTV, false, true><<<g, 256, 0, c.st>>>(p); else k_lin<NTV, false, false><<<g, 256, 0, c.st>>>(p); }     \
+        if (mm == 1) { if (tiled) k_lin<NTV, 1, true><<<g, 256, 0, c.st>>>(p); else k_lin<NTV, 1, false><<<g, 256, 0, c.st>>>(p); }      \
+        else if (mm == 2) { if (tiled) k_lin<NTV, 2, true><<<g, 256, 0, c.st>>>(p); else k_lin<NTV, 2, false><<<g, 256, 0, c.st>>>(p); } \
+        else { if (tiled) k_lin<NTV, 0, true><<<g, 256, 0, c.st>>>(p); else k_lin<NTV, 0, false><<<g, 256, 0, c.st>>>(p); }     \
     } while (0)
     if (ring) {
         p.gy = nOT / nt;
         const dim3 g1((unsigned)((gx + 7) / 8 * 8 * p.gy));
         // 3x3 on 32-wide views (a wave's 32 tokens = one image row): the row fragments are loaded once per tap row (k_linr<.., KS>)
         const int ks3 = (v.taps == 9 && c.d.w == 32 && (v.KS == 4 || v.KS == 8)) ? v.KS : 0;
-#define LFT_LAUNCH_R(NTV, KSV) do { if (m3) k_linr<NTV, true, KSV><<<g1, 256, 0, c.st>>>(p); else k_linr<NTV, false, KSV><<<g1, 256, 0, c.st>>>(p); } while (0)
+#define LFT_LAUNCH_R(NTV, KSV) do { if (mm == 1) k_linr<NTV, 1, KSV><<<g1, 256, 0, c.st>>>(p); else if (mm == 2) k_linr<NTV, 2, KSV><<<g1, 256, 0, c.st>>>(p); else k_linr<NTV, 0, KSV><<<g1, 256, 0, c.st>>>(p); } while (0)
         if (nt == 4) { if (ks3 == 4) LFT_LAUNCH_R(4, 4); else LFT_LAUNCH_R(4, 0); }     // (no 3x3 view has 128 inputs and 128 outputs)
         else { if (ks3 == 4) LFT_LAUNCH_R(2, 4); else if (ks3 == 8) LFT_LAUNCH_R(2, 8); else LFT_LAUNCH_R(2, 0); }
 #undef LFT_LAUNCH_R
@@ -284,7 +286,7 @@ int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, in
     int nch = std::min<long long>(std::min(kWgChunksMax, rounds * slots / gridy), std::max<long long>(base, N / 256));
     // split-bf16 products are 5x cheaper, the loop is bound by its loads and conversions and a workgroup's epilogue (LDS sum of
     // the four waves, partial image) weighs more: measured, more chunks pay only where the launch filled under a quarter of the chip
-    if (c.math == LFT_MATH_BF16X3 && base * gridy * 4 > slots) nch = base;
+    if (c.math == LFT_MATH_BF16X3 && base * gridy * 4 > slots) nch = base;       // (bf16x6: measured, no difference either way)
     nch = std::max(nch, 1);
     long long len = (N + nch - 1) / nch;
     len = (len + 63) & ~63LL;
@@ -297,13 +299,14 @@ int wgrad(const TrainCtx& c, const float* dY, int Co, const float* X, int Ci, in
     if (int ok_ = c.launch_ok()) return ok_;
     hipStream_t ws = c.st;
     WgP p{dY, Co, X, Ci, c.F(c.T.part) + poff, wsize, Ci * taps, taps, 1, Co, Ci, taps, c.d.h, c.d.w, N, len, 1, nch, 1};
-    const bool m3 = c.math == LFT_MATH_BF16X3;
+    const int mm = c.math == LFT_MATH_BF16X3 ? 1 : c.math == LFT_MATH_BF16X6 ? 2 : 0;
 #define LFT_LAUNCH_WG(NIV, TXV)                                                                                        \
     do {                                                                                                               \
         const size_t lds = (size_t)3 * TXV * NIV * 16 * 64 * sizeof(float);                                            \
         const dim3 g((unsigned)((nch + 7) / 8 * 8 * p.gy * TXV));                                                       \
-        if (m3) { if ((rc = allow_lds(k_wgrad<NIV, true, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, true, TXV><<<g, 256, lds, ws>>>(p); }   \
-        else { if ((rc = allow_lds(k_wgrad<NIV, false, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, false, TXV><<<g, 256, lds, ws>>>(p); }    \
+        if (mm == 1) { if ((rc = allow_lds(k_wgrad<NIV, 1, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, 1, TXV><<<g, 256, lds, ws>>>(p); }   \
+        else if (mm == 2) { if ((rc = allow_lds(k_wgrad<NIV, 2, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, 2, TXV><<<g, 256, lds, ws>>>(p); }   \
+        else { if ((rc = allow_lds(k_wgrad<NIV, 0, TXV>, lds, "k_wgrad"))) return rc; k_wgrad<NIV, 0, TXV><<<g, 256, lds, ws>>>(p); }    \
     } while (0)
     if (taps == 9) {
         p.igroups = 1; p.gy = Co / 32;
@@ -417,7 +420,7 @@ int train_forward(const float* const* P, const float* lr, float* out, float* tap
     const int nimg = d.B * d.V;
     int rc;
 #define TRY(x) do { if ((rc = (x))) return rc; } while (0)
-    if (math == LFT_MATH_BF16X3) TRY(run_pack_split(ops, c.F(T.wp), (int)WV.nfrags, st));
+    if (math == LFT_MATH_BF16X3 || math == LFT_MATH_BF16X6) TRY(run_pack_split(ops, c.F(T.wp), (int)WV.nfrags, st, math == LFT_MATH_BF16X6));
     else TRY(run_pack<float>(ops, c.F(T.wp), (int)WV.nfrags, st));   // both orientations of every matrix, for this step's weights
     k_pe_plain<<<blocks_for(std::max(d.V, d.hw) * 64, 256), 256, 0, st>>>(c.F(T.pe_ang), c.F(T.pe_spa), d.V, d.h, d.w);
     LFT_LAUNCH_OK("k_pe_plain");

@@ -54,7 +54,7 @@ def _ptr_array(ps):
     return (ctypes.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
 
 
-MATH = {"fp32": _lib.MATH_F32, "bf16x3": _lib.MATH_BF16X3}
+MATH = {"fp32": _lib.MATH_F32, "bf16x3": _lib.MATH_BF16X3, "bf16x6": _lib.MATH_BF16X6}
 # HIP-graph captures use the thread-local error mode: with a process group alive, torch's NCCL watchdog THREAD polls its work
 # events (hipEventQuery) at any time; under the default global mode such a call from another thread while this thread captures
 # invalidates the capture ("operation not permitted when stream is capturing" -- seen once in round 4 on the RCCL test, a race
@@ -63,7 +63,7 @@ CAPTURE_MODE = "thread_local"
 
 
 def train_forward(ps, lr, A, s, tape=None, math="fp32"):
-    """lft_train_forward: returns (out, tape).  math: 'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 products)."""
+    """lft_train_forward: returns (out, tape).  math: 'fp32' (exact fp32 MFMA), 'bf16x6' (fp32-class six-product split) or 'bf16x3' (split-bf16 products)."""
     B, _, H, W = lr.shape
     h, w = H // A, W // A
     dev = lr.device

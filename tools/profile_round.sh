@@ -16,7 +16,7 @@ cp "$stats" $out/${tag}_kernel_stats.csv
 python3 tools/collect_traffic.py $out/pmc_fetch $out/pmc_write $out/${tag}_hbm_traffic.json > $out/${tag}_hbm_traffic.txt
 python3 tools/pmc_summary.py $out/pmc_sq > $out/${tag}_pmc_sq.txt
 # the training step (BASELINE configs[2] shape, B = 8): kernel trace of 10 steps per math mode, PMC passes of 2 eager steps
-for math in bf16x3 fp32; do
+for math in bf16x3 bf16x6 fp32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/train_trace_$math -- python3 tools/train_bench.py --math $math --steps 10 --warmup 3 --no-graph > $out/train_trace_$math.log 2>&1
   cp "$(find $out/train_trace_$math -name "*kernel_stats.csv" | head -1)" $out/${tag}_train_kernel_stats_$math.csv
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/train_fetch_$math -- python3 tools/train_bench.py --math $math --steps 2 --warmup 0 --no-graph > $out/train_fetch_$math.log 2>&1

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--lr", type=int, default=32)
     ap.add_argument("--scale", type=int, default=2, choices=[2, 4])
     ap.add_argument("--phases", action="store_true")
-    ap.add_argument("--math", default="bf16x3", choices=["fp32", "bf16x3"])
+    ap.add_argument("--math", default="bf16x3", choices=["fp32", "bf16x3", "bf16x6"])
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
     from lft_amd import dp, train as T

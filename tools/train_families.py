@@ -9,7 +9,7 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 
-for math in ("bf16x3", "fp32"):
+for math in (sys.argv[1:] or ["bf16x3", "fp32"]):
     t = bench.train_object(torch.device("cuda", 0), math, with_roofline=True)
     r = t["roofline"]
     print(math, "step ms", round(t["ms_per_step"], 2), "patches/s", round(t["patches_per_s"], 1), r["families_ms"], "dominant", r["kernel"], r["bound"],
