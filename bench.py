@@ -739,11 +739,11 @@ def main():
                 pd = {}
                 for fam, fmax in (("hard_scenes", 0.25), ("smooth_scenes", 0.06)):
                     sd_t, hist = PU.train_small_model(dev, fmax=fmax)
-                    r = PU.psnr_delta(dev, sd_t, PU.held_out_scenes(n=1, fmax=fmax))
+                    r = PU.psnr_delta(dev, sd_t, PU.held_out_scenes(n=1, size=32, fmax=fmax))
                     pd[fam] = {"train_loss_first_last": [hist[0], hist[-1]], **{p: {k: round(v, 5) if isinstance(v, float) else v for k, v in d.items()} for p, d in r.items()}}
                 result["psnr_delta_db"] = dict(pd, tolerance_db=0.01,
                                                note="max over views of |PSNR(path, HR) - PSNR(oracle, HR)|; A5 2x model trained in this run (20 epochs, synthetic light fields), "
-                                                    "one held-out 5x5x48x48 scene per family through LFdivide / network / LFintegrate")
+                                                    "one held-out 5x5x32x32 scene per family through LFdivide / network / LFintegrate")
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

@@ -18,7 +18,7 @@ def test_psnr_delta_within_a_hundredth_of_a_db_on_trained_weights(fmax):
     dev = torch.device("cuda:0")
     sd, hist = PU.train_small_model(dev, fmax=fmax)
     assert hist[-1] < 0.6 * hist[0], f"the small model did not train: {hist[0]:.4f} -> {hist[-1]:.4f}"
-    scenes = PU.held_out_scenes(n=1, fmax=fmax)
+    scenes = PU.held_out_scenes(n=1, size=32, fmax=fmax)          # 5 x 5 views of 32 x 32 LR: four overlapping patches
     res = PU.psnr_delta(dev, sd, scenes)
     for prec, r in res.items():
         print(f"psnr_delta_db [{prec}]: max {r['max_abs_delta_db']:.5f} mean {r['mean_abs_delta_db']:.5f} dB over {r['views']} views; "

@@ -47,9 +47,8 @@ def make_inputs(A, s, B, h, w):
 MATHS = ["fp32", "bf16x3", "bf16x6"]   # exact fp32 MFMA / split-bf16 products / fp32-class six-product weight gradients: same tolerance for all
 
 
-@pytest.fixture(scope="module", params=[(c, m) for c in CASES for m in MATHS], ids=lambda cm: "A%d_s%d_B%d_%dx%d" % cm[0] + "_" + cm[1])
-def case(request):
-    (A, s, B, h, w), math = request.param
+def build_case(param):
+    (A, s, B, h, w), math = param
     sd_np, lr, hr = make_inputs(A, s, B, h, w)
     sd = O.state_from_numpy(sd_np)
     taps = {}
@@ -68,6 +67,23 @@ def case(request):
     torch.cuda.synchronize()
     return dict(math=math, sd=sd, A=A, s=s, B=B, h=h, w=w, names=names, ps=ps, lr=lr_d, hr=hr_d, out=out, tape=tape, flat=flat, loss=float(scratch[1024]),
                 taps=taps, out_ref=out_ref, loss_ref=float(loss_ref), grads_ref=grads_ref, dout=dout)
+
+
+_CASE_ID = lambda cm: "A%d_s%d_B%d_%dx%d" % cm[0] + "_" + cm[1]      # noqa: E731
+
+
+@pytest.fixture(scope="module", params=[(c, m) for c in CASES for m in MATHS], ids=_CASE_ID)
+def case(request):
+    return build_case(request.param)
+
+
+# the per-block backward tests: three shapes (2x, 4x with h != w, 5 x 5 views) x the three math modes -- every backward kernel runs in each
+BLOCK_CASES = [(3, 2, 2, 6, 6), (2, 4, 1, 8, 5), (5, 2, 1, 8, 8)]
+
+
+@pytest.fixture(scope="module", params=[(c, m) for c in BLOCK_CASES for m in MATHS], ids=_CASE_ID)
+def block_case(request):
+    return build_case(request.param)
 
 
 def test_forward_tape_matches_oracle(case):
@@ -131,7 +147,8 @@ BLOCKS = [("upsample", _lib.BLOCK_UPSAMPLE, 0), ("spa", _lib.BLOCK_SPA, 1), ("sp
 
 
 @pytest.mark.parametrize("kind,block,layer", BLOCKS, ids=[f"{k}{l}" for k, _, l in BLOCKS])
-def test_block_backward_matches_oracle_autograd(case, kind, block, layer):
+def test_block_backward_matches_oracle_autograd(block_case, kind, block, layer):
+    case = block_case
     """lft_train_block_backward (the `_bwd` counterpart of the per-stage forward entry points): ONE block's backward kernels against
     autograd over the oracle's function of that block alone -- its input is our tape's activation, its incoming gradient a random
     tensor, its ReLU / LeakyReLU branches ours (O.branch_masks), so nothing depends on the rest of the network or on a kink."""
