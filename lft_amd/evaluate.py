@@ -44,3 +44,21 @@ def test(net, scenes: Iterable[Tuple[torch.Tensor, torch.Tensor]], patch: int = 
         dist.all_reduce(t)
         acc = t.cpu().numpy()
     return float(acc[0] / acc[2]), float(acc[1] / acc[2])
+
+
+def test_sets(net, args, log=print, patch: int = None, stride: int = None, ssim_range: float = 2.0):
+    """The reference's test.py main loop (:60-69) over the test tree of utils_datasets.MultiTestSetDataLoader:
+    ``<path_for_test>/SR_{A}x{A}_{s}x/<dataset>/<scene>.h5`` read by lft_amd.datasets (h5lite), every scene through `test_scene`.
+    args: path_for_test, angRes, scale_factor (+ patch_size_for_test / stride_for_test as option.py names them).
+    Returns {dataset: (psnr, ssim)} in the loader's order and logs the reference's line per dataset."""
+    from . import datasets
+    patch = patch or getattr(args, "patch_size_for_test", 32)
+    stride = stride or getattr(args, "stride_for_test", 16)
+    names, loaders, _ = datasets.MultiTestSetDataLoader(args)
+    out = {}
+    for name, loader in zip(names, loaders):
+        scenes = ((lr.squeeze(), hr.squeeze()) for lr, hr in loader)                       # test.py:76-77
+        p, s = test(net, scenes, patch, stride, ssim_range)
+        out[name] = (p, s)
+        log("Test on %s, psnr/ssim is %.2f/%.3f" % (name, p, s))                           # test.py:66
+    return out

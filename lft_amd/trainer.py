@@ -5,8 +5,8 @@ The per-batch skimage PSNR/SSIM of train.py:121-124 is not part of the step (SUR
 mean loss and the PSNR of the last batch computed on the GPU.
 
 Data comes from a *patch source*: anything with ``__len__`` and ``get(indices) -> (lr [n,1,A*p,A*p], hr [n,1,A*p*s,A*p*s])``
-float32 tensors.  ``TensorPatchSource`` wraps arrays already in memory (e.g. converted from the reference's
-``Lr_SAI_y`` / ``Hr_SAI_y`` .h5 patches by a machine that has h5py: this image has none, see DESIGN.md section 10);
+float32 tensors.  ``TensorPatchSource`` wraps arrays already in memory; ``lft_amd.datasets.H5PatchSource`` reads the reference's
+``Lr_SAI_y`` / ``Hr_SAI_y`` .h5 training tree (own HDF5 reader, DESIGN.md section 10);
 ``SyntheticPatchSource`` makes band-limited random light fields for rehearsals and benchmarks.
 """
 from __future__ import annotations

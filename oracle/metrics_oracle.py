@@ -3,9 +3,13 @@
 
 The arithmetic lives in scikit-image (``skimage.metrics.peak_signal_noise_ratio`` / ``structural_similarity(...,
 gaussian_weights=True)``), which is NOT vendored in /root/reference, has no pinned version there (README.md lists only
-PyTorch / torchvision) and is not installed in this image: **parity unpinned** -- this file restates the published
-algorithm (Wang et al. 2004 as implemented by scikit-image 0.16-0.18, the releases contemporary with the reference's
-PyTorch 1.3) on top of scipy.ndimage.gaussian_filter, the very function scikit-image calls:
+PyTorch / torchvision) and is not importable by the interpreter this framework runs on.  The image does carry an Anaconda
+Python 3.9 under /opt/conda with scikit-image 0.18.3 (a release contemporary with the reference's PyTorch 1.3-1.8):
+**pinned** by tests/golden/metrics_skimage.npz -- the reference's own two calls per view (utils.py:79-83) made with that
+scikit-image on seeded mosaics (tools/gen_golden_skimage.py; views of 11x11 .. 64x64, non-square, 81 views, a label with
+negative values, MSE = 0 views) -- which this file reproduces to the bit (tests/test_metrics_oracle.py).  It restates the
+published algorithm (Wang et al. 2004 as implemented by scikit-image 0.16-0.18) on top of scipy.ndimage.gaussian_filter, the
+very function scikit-image calls:
   * PSNR: 10 log10(R^2 / MSE), MSE in float64, R = 1 for float images whose minimum is >= 0 (else 2);
   * SSIM: sigma 1.5, truncate 3.5 -> 11x11 Gaussian window, sample covariance (N/(N-1), N = 121), K1 0.01, K2 0.03,
     data_range R = 2 for float images in those releases (dtype range [-1, 1]; newer releases require an explicit

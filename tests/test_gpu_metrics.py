@@ -1,5 +1,7 @@
-"""GPU: per-view PSNR / SSIM kernels (C ABI lft_view_metrics) against the scipy-based restatement of the scikit-image
-algorithm the reference calls (oracle/metrics_oracle.py; utils/utils.py:56-88)."""
+"""GPU: per-view PSNR / SSIM kernels (C ABI lft_view_metrics) against scikit-image's own results (tests/golden/metrics_skimage.npz:
+the reference's two calls per view, utils/utils.py:79-83, made with scikit-image 0.18.3) and against the restatement that fixture
+pins (oracle/metrics_oracle.py)."""
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -10,6 +12,24 @@ from lft_amd import metrics
 from oracle import metrics_oracle as M
 
 pytestmark = pytest.mark.gpu
+FIX = np.load(os.path.join(os.path.dirname(__file__), "golden", "metrics_skimage.npz"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in FIX["names"]])
+def test_view_metrics_match_scikit_image_fixture(name):
+    A = int(FIX[name + "/A"])
+    label, out = torch.from_numpy(FIX[name + "/label"]).cuda(), torch.from_numpy(FIX[name + "/out"]).cuda()
+    p, s = metrics.view_metrics(label, out, A)
+    p, s = p.cpu().numpy().reshape(FIX[name + "/psnr"].shape), s.cpu().numpy().reshape(FIX[name + "/ssim"].shape)
+    eP, eS = FIX[name + "/psnr"], FIX[name + "/ssim"]
+    fin = np.isfinite(eP)
+    assert np.array_equal(np.isinf(p), np.isinf(eP)) and np.array_equal(np.isnan(p), np.isnan(eP)), (p, eP)   # MSE 0 (exactly reproduced view, all-zero view): inf
+    assert np.abs(p[fin] - eP[fin]).max() <= 1e-4                      # dB
+    assert np.abs(s - eS).max() <= 2e-6
+    pm, sm = metrics.cal_metrics(SimpleNamespace(angRes=A), label, out)
+    epm, esm = float(FIX[name + "/psnr_mean"]), float(FIX[name + "/ssim_mean"])
+    assert (np.isinf(epm) and np.isinf(pm)) or abs(pm - epm) <= 1e-4
+    assert abs(sm - esm) <= 2e-6
 
 
 @pytest.mark.parametrize("B,A,h,w,rng", [(2, 3, 40, 33, 2.0), (1, 2, 64, 64, 1.0), (1, 5, 11, 17, 2.0)])

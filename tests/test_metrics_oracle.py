@@ -1,8 +1,32 @@
-"""CPU: sanity of the metrics restatement (oracle/metrics_oracle.py).  scikit-image is absent here, so the restatement
-is pinned only by properties of the published definitions: identical images, known MSE, window normalisation."""
+"""CPU: the metrics restatement (oracle/metrics_oracle.py) against the REAL scikit-image: tests/golden/metrics_skimage.npz holds
+seeded mosaics and the results of the reference's own two calls per view (utils/utils.py:79-83) made with scikit-image 0.18.3
+(tools/gen_golden_skimage.py, run under the image's /opt/conda Python 3.9 -- the only interpreter here that has scikit-image).
+Plus properties of the published definitions: identical images, known MSE, window normalisation."""
+import os
+
 import numpy as np
+import pytest
 
 from oracle import metrics_oracle as M
+
+FIX = np.load(os.path.join(os.path.dirname(__file__), "golden", "metrics_skimage.npz"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in FIX["names"]])
+def test_oracle_matches_scikit_image_fixture(name):
+    """Per-view PSNR / SSIM and the `> 0` means of cal_metrics, incl. an exactly reproduced view and an all-zero view (MSE 0:
+    PSNR inf, and so is the mean), a label with negative values (data range 2), non-square and 11x11 views.  float32 results as the
+    reference stores them; the restatement calls the same scipy Gaussian filter scikit-image does, so the agreement is to the bit."""
+    A = int(FIX[name + "/A"])
+    with np.errstate(all="ignore"):
+        P, S, pm, sm = M.cal_metrics(FIX[name + "/label"], FIX[name + "/out"], A)
+    eP, eS = FIX[name + "/psnr"], FIX[name + "/ssim"]
+    assert np.array_equal(np.isnan(P), np.isnan(eP)) and np.array_equal(np.isinf(P), np.isinf(eP))
+    fin = np.isfinite(eP)
+    assert np.abs(P[fin] - eP[fin]).max() <= 1e-5 and np.abs(S - eS).max() <= 1e-7
+    epm, esm = float(FIX[name + "/psnr_mean"]), float(FIX[name + "/ssim_mean"])
+    assert (np.isinf(epm) and np.isinf(pm)) or abs(pm - epm) <= 1e-5
+    assert abs(sm - esm) <= 1e-7
 
 
 def test_psnr_known_value_and_range_rule():

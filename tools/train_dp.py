@@ -3,6 +3,8 @@
   python tools/train_dp.py --angRes 5 --scale_factor 2 --batch_size 8 --epoch 50 --data patches.npz --path_log ./log
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 tools/train_dp.py ...
 
+--path_for_train DIR: the reference's own training tree (DIR/SR_AxA_sx/<dataset>/*.h5 with Lr_SAI_y / Hr_SAI_y, as
+Generate_Data_for_Training.m writes it), read by lft_amd.h5lite (--data_name as in option.py).
 --data: an .npz with arrays Lr_SAI_y [n, A*32, A*32] and Hr_SAI_y [n, A*32*s, A*32*s] (the two datasets of the
 reference's training .h5 patches, stacked); --synthetic N instead makes N band-limited random light fields."""
 import argparse, os, sys
@@ -31,6 +33,8 @@ def main():
     ap.add_argument("--decay_rate", type=float, default=0.0, help="Adam weight_decay, as the reference's option.py")
     ap.add_argument("--epoch", type=int, default=50)
     ap.add_argument("--data", default=None)
+    ap.add_argument("--path_for_train", default=None, help="the reference's training tree (./data_for_train/): SR_AxA_sx/<dataset>/*.h5, read by lft_amd.h5lite")
+    ap.add_argument("--data_name", default="ALL")
     ap.add_argument("--synthetic", type=int, default=0)
     ap.add_argument("--max_batches", type=int, default=0)
     args = ap.parse_args()
@@ -49,7 +53,10 @@ def main():
         start = trainer.load_checkpoint(net, args.path_pre_pth)
     else:
         net.apply(MODEL.weights_init)
-    if args.data:
+    if args.path_for_train:
+        from lft_amd import datasets
+        src = datasets.H5PatchSource(args.path_for_train, args.angRes, args.scale_factor, args.data_name, cache=True)
+    elif args.data:
         z = np.load(args.data)
         src = trainer.TensorPatchSource(torch.from_numpy(z["Lr_SAI_y"]), torch.from_numpy(z["Hr_SAI_y"]))
     else:
