@@ -22,7 +22,6 @@ Pinned by files written with the real h5py / libhdf5 (tests/golden/h5/, tools/ge
 from __future__ import annotations
 
 import mmap
-import struct
 import zlib
 from typing import Dict, List, Optional, Tuple
 
@@ -205,10 +204,11 @@ class File(Group):
                 c = _Buf(self._mm, p)
                 end = p + n
                 while c.p + 4 <= end:
-                    t, sz, _fl = c.u(1), c.u(2), c.u(1)
+                    t, sz, mfl = c.u(1), c.u(2), c.u(1)
                     if flags & 0x04:
                         c.skip(2)
                     body = c.raw(sz)
+                    self._no_shared(t, mfl, addr)
                     if t == 0x10:
                         q = _Buf(body)
                         a, ln = q.u(self.O), q.u(self.L)
@@ -231,9 +231,10 @@ class File(Group):
             p, n = blocks.pop(0)
             c = _Buf(self._mm, p)
             while c.p + 8 <= p + n:
-                t, sz = c.u(2), c.u(2)
-                c.skip(4)
+                t, sz, mfl = c.u(2), c.u(2), c.u(1)
+                c.skip(3)
                 body = c.raw(sz)
+                self._no_shared(t, mfl, addr)
                 if t == 0x10:
                     q = _Buf(body)
                     a, ln = q.u(self.O), q.u(self.L)
@@ -241,6 +242,12 @@ class File(Group):
                 elif t != 0:
                     msgs.append((t, body))
         return msgs
+
+    @staticmethod
+    def _no_shared(t: int, mflags: int, addr: int) -> None:
+        # a shared message's body is a reference to the real message (committed datatypes, shared-message heaps): not in the subset
+        if mflags & 0x02 and t in (0x0001, 0x0003, 0x0005, 0x0008, 0x000B):
+            raise H5Error(f"object header at {addr:#x}: shared header message (type {t:#x}) not supported")
 
     def _object(self, addr: int, name: str):
         if addr in self._cache:

@@ -65,6 +65,11 @@ def test_errors_are_named_not_garbage(tmp_path):
         h5lite.File(str(p))
     with pytest.raises(h5lite.H5Error, match="read-only"):
         h5lite.File(os.path.join(DIR, "many.h5"), "w")
+    # a feature outside the subset (the dataset's datatype is a shared, committed one): refused by name, not misread
+    with h5lite.File(os.path.join(DIR, "unsupported_shared_dtype.h5")) as hf:
+        assert sorted(hf.keys()) == ["mytype", "x"]
+        with pytest.raises(h5lite.H5Error, match="shared header message"):
+            hf["x"]
     # a truncated file: the header parses, the data is beyond the end
     raw = open(os.path.join(DIR, "train_000001.h5"), "rb").read()
     p.write_bytes(raw[:len(raw) // 2])

@@ -95,6 +95,10 @@ def main():
     with h5py.File(os.path.join(OUT, "userblock.h5"), "w", libver="earliest", userblock_size=512) as hf:
         hf.create_dataset("Lr_SAI_y", data=lr[:10, :10].copy())
     record("userblock.h5")
+    # 6a. outside the reader's subset, to be refused by name: a dataset whose datatype is a shared (committed) one
+    with h5py.File(os.path.join(OUT, "unsupported_shared_dtype.h5"), "w", libver="earliest") as hf:
+        hf["mytype"] = np.dtype("f4")
+        hf.create_dataset("x", data=np.arange(4, dtype="f4"), dtype=hf["mytype"])
     # 6b. a test scene large enough for the reference's 32 / 16 patch tiling (test.py:75-104): 2 x 2 views of 40 x 36 (LR), 2x,
     #     smooth content so that metrics mean something; written as Generate_Data_for_Test.m does (transposed, Hr first)
     yy, xx = np.meshgrid(np.linspace(0, 1, 80), np.linspace(0, 1, 72), indexing="ij")
