@@ -215,6 +215,7 @@ class TrainStep:
         broadcast_(self.flat_params, src=0, group=self.group)
         self.t = 0
         self._tape = None
+        self.last_out = None               # [B,1,A*h*s,A*w*s]: what the network produced in the last step (before the update), for per-batch metrics
         self._scratch = torch.empty(1024 + 1, dtype=torch.float32, device=dev)
 
     def _fwd_loss_bwd(self, lr_in, hr, tape, dout, loss, on_bucket=None):
@@ -309,12 +310,13 @@ class TrainStep:
                     graph.replay()
                     if exchange:
                         start_bucket(b, *g["buckets"][b])
+                self.last_out = g["out"]                       # SR output of this step's forward (overwritten by the next step of this shape)
             else:
                 nb = tape_bytes(B, self.A, h, w, self.s)
                 if self._tape is None or self._tape.numel() != nb:
                     self._tape = torch.empty(nb, dtype=torch.uint8, device=dev)
-                self._fwd_loss_bwd(lr_in.contiguous().float(), hr.contiguous().float(), self._tape, torch.empty_like(hr), loss,
-                                   on_bucket=start_bucket if exchange else None)
+                self.last_out = self._fwd_loss_bwd(lr_in.contiguous().float(), hr.contiguous().float(), self._tape, torch.empty_like(hr), loss,
+                                                   on_bucket=start_bucket if exchange else None)
             dp.sum_gradients_finish(handles)                   # the Adam kernel is ordered after the collectives
             gscale = dp.grad_scale(self.group) if exchange else 1.0
             stream = torch.cuda.current_stream(dev).cuda_stream

@@ -141,9 +141,14 @@ def psnr_gpu(sr: torch.Tensor, hr: torch.Tensor) -> float:
 
 def fit(net, source, epochs: int, batch_size: int, lr: float = 2e-4, n_steps: int = 15, gamma: float = 0.5,
         start_epoch: int = 0, ckpt_dir: Optional[str] = None, model_name: str = "LFT", seed: int = 0,
-        use_augmentation: bool = True, log=print, max_batches_per_epoch: Optional[int] = None, decay_rate: float = 0.0):
+        use_augmentation: bool = True, log=print, max_batches_per_epoch: Optional[int] = None, decay_rate: float = 0.0,
+        batch_metrics: bool = False, ssim_range: float = 2.0):
     """Train ``net`` (lft_amd.module.get_model on this rank's GPU) like reference train.py:86-110.  ``batch_size`` is
-    the GLOBAL batch (reference --batch_size).  Returns the list of per-epoch mean losses (global)."""
+    the GLOBAL batch (reference --batch_size).  Returns the list of per-epoch mean losses (global).
+    batch_metrics: also compute the reference's per-batch ``cal_metrics(args, label, out)`` (train.py:121-124: per-view PSNR / SSIM of
+    the step's own output, means over positive views, then the mean over the epoch's batches) -- on the GPU (lft_view_metrics), with
+    no host synchronisation inside the epoch -- and log the reference's line ('... loss is: %.5f, psnr is %.5f, ssim is %.5f');
+    ``fit.last_metrics`` then holds the per-epoch (psnr, ssim) pairs."""
     import torch.distributed as dist
     from .train import TrainStep
     rank, _, world = dp.env_world()
@@ -152,29 +157,40 @@ def fit(net, source, epochs: int, batch_size: int, lr: float = 2e-4, n_steps: in
     dev = next(net.parameters()).device
     ts = TrainStep(net, lr=lr, weight_decay=decay_rate)            # reference train.py:82 weight_decay=args.decay_rate
     history = []
+    fit.last_metrics = []
     for epoch in range(start_epoch, epochs):
         ts.lr = step_lr(lr, epoch, n_steps, gamma)
         rng = np.random.Generator(np.random.PCG64([seed, epoch, rank, 17]))
         batches = epoch_batches(len(source), batch_size, epoch, seed, rank, world)
         if max_batches_per_epoch:
             batches = batches[:max_batches_per_epoch]
-        total = torch.zeros(1, device=dev)
+        total = torch.zeros(3 if batch_metrics else 1, device=dev)
         last = None
         for ix in batches:
             a, b = source.get(ix)
             a, b = a.to(dev, non_blocking=True), b.to(dev, non_blocking=True)
             if use_augmentation:
                 a, b = augment(a, b, rng)
-            total += ts.step(a, b)
+            loss = ts.step(a, b)
+            if batch_metrics:
+                from . import metrics
+                p, s = metrics.view_metrics(b, ts.last_out, net.angRes, ssim_range)
+                total += torch.stack([loss[0], p.sum() / (p > 0).sum(), s.sum() / (s > 0).sum()])
+            else:
+                total += loss
             last = (a, b)
         mean = total / max(1, len(batches))
         if world > 1:
             host = mean.cpu() if dist.get_backend() == "gloo" else mean
             dist.all_reduce(host)
             mean = host.to(dev) / world
-        history.append(float(mean))
-        msg = "The %dth Train, loss is: %.5f, lr %.3g" % (epoch + 1, history[-1], ts.lr)
-        if last is not None:
+        history.append(float(mean[0]))
+        if batch_metrics:
+            fit.last_metrics.append((float(mean[1]), float(mean[2])))
+            msg = "The %dth Train, loss is: %.5f, psnr is %.5f, ssim is %.5f" % (epoch + 1, history[-1], *fit.last_metrics[-1])   # train.py:90-91
+        else:
+            msg = "The %dth Train, loss is: %.5f, lr %.3g" % (epoch + 1, history[-1], ts.lr)
+        if last is not None and not batch_metrics:
             with torch.no_grad():
                 msg += ", psnr(last batch) %.3f" % psnr_gpu(net(last[0]), last[1])
         if rank == 0:

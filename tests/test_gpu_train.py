@@ -491,6 +491,38 @@ def test_fit_trains_and_writes_reference_format_checkpoints(tmp_path):
         assert torch.equal(fresh(lr), net.eval()(lr))
 
 
+def test_fit_batch_metrics_are_the_reference_loops_cal_metrics(tmp_path):
+    """fit(batch_metrics=True) = the reference's per-batch cal_metrics(args, label, out) of train.py:121-124 on the step's own output
+    (before the update), averaged over the epoch's batches: replayed here step by step against the scikit-image-pinned oracle."""
+    from model import LFT
+    from lft_amd import trainer
+    from lft_amd.train import TrainStep
+    from oracle import metrics_oracle as MO
+    A, s = 2, 2
+    torch.manual_seed(3)
+    net = LFT.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=s)).to(G.DEV)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    src = trainer.SyntheticPatchSource(8, A, s, patch=16, seed=2, device=G.DEV)
+    logs = []
+    hist = trainer.fit(net, src, epochs=2, batch_size=4, lr=5e-4, use_augmentation=False, log=logs.append, batch_metrics=True)
+    assert len(trainer.fit.last_metrics) == 2 and "psnr is" in logs[0] and "ssim is" in logs[0]
+    # replay: same weights, same batches, the oracle's metrics of every step's output
+    net2 = LFT.get_model(SimpleNamespace(channels=64, angRes=A, scale_factor=s)).to(G.DEV)
+    net2.load_state_dict(state)
+    ts = TrainStep(net2, lr=5e-4)
+    for epoch in range(2):
+        ts.lr = trainer.step_lr(5e-4, epoch)
+        acc = []
+        for ix in trainer.epoch_batches(len(src), 4, epoch, 0, 0, 1):
+            a, b = src.get(ix)
+            loss = float(ts.step(a, b))
+            _, _, pm, sm = MO.cal_metrics(b.cpu().numpy(), ts.last_out.cpu().numpy(), A)
+            acc.append((loss, pm, sm))
+        m = np.mean(np.array(acc), axis=0)
+        assert abs(m[0] - hist[epoch]) < 1e-6
+        assert abs(m[1] - trainer.fit.last_metrics[epoch][0]) < 2e-4 and abs(m[2] - trainer.fit.last_metrics[epoch][1]) < 5e-6, (m, trainer.fit.last_metrics)
+
+
 @pytest.mark.parametrize("hw", [(32, 32), (33, 35), (26, 32)], ids=["32x32", "33x35_ragged", "26x32_rows_across_workgroups"])
 @pytest.mark.parametrize("math", MATHS)
 def test_full_size_backward_properties_cfg3(math, hw):

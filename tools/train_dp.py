@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--data_name", default="ALL")
     ap.add_argument("--synthetic", type=int, default=0)
     ap.add_argument("--max_batches", type=int, default=0)
+    ap.add_argument("--batch_metrics", action="store_true", help="per-batch PSNR / SSIM of train.py:121-124 (on the GPU) and the reference's epoch line")
     args = ap.parse_args()
     import importlib
     from lft_amd import dp, trainer
@@ -64,7 +65,7 @@ def main():
     ckpt_dir = os.path.join(args.path_log, "SR_%dx%d_%dx" % (args.angRes, args.angRes, args.scale_factor), args.model_name, "checkpoints")
     trainer.fit(net, src, args.epoch, args.batch_size, lr=args.lr, n_steps=args.n_steps, gamma=args.gamma, start_epoch=start,
                 ckpt_dir=ckpt_dir, model_name=args.model_name, max_batches_per_epoch=args.max_batches or None,
-                decay_rate=args.decay_rate)
+                decay_rate=args.decay_rate, batch_metrics=args.batch_metrics)
 
 
 if __name__ == "__main__":
