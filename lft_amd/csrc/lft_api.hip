@@ -344,7 +344,7 @@ int pack_impl(const float* const* P, void* packed, const Dims& d, int prec, hipS
 }
 
 void launch_assemble(const float* lr, const float* g, float* out, int B, int A, int h, int w, int s, hipStream_t st, int gld = 0, unsigned* status = nullptr) {
-    const dim3 tg((unsigned)((A * w + 7) / 8), (unsigned)((A * h + 7) / 8), (unsigned)B);      // 8 x 8 LR mosaic pixels per workgroup
+    const dim3 tg((unsigned)((A * w + 7) / 8) * (unsigned)((A * h + 7) / 8) * (unsigned)B);    // 8 x 8 LR mosaic pixels per workgroup; tile order: k_assemble_t
     if (!gld) gld = (s + 2) * (s + 2);
     if (s == 2) k_assemble_t<2><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w, gld, status);
     else k_assemble_t<4><<<tg, 256, 0, st>>>(lr, g, out, B, A, h, w, gld, status);

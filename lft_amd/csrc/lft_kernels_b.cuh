@@ -809,7 +809,11 @@ __global__ __launch_bounds__(256) void k_assemble_t(const float* __restrict__ lr
     constexpr int TL = 8, HL = TL + 2, GP = (S + 2) * (S + 2), P4 = GP / 4, TS = TL * S;
     __shared__ __attribute__((aligned(16))) float gs[HL * HL * GP];
     const int MH = A * h, MW = A * w, HR_W = MW * S, HR_H = MH * S;
-    const int by0 = blockIdx.y * TL, bx0 = blockIdx.x * TL, b = blockIdx.z;
+    // 1-D grid, XCD-aware: neighbouring blocks stage 36 of each other's 100 footprints -- with the round-robin placement every one of
+    // those came from beyond an L2 once per block that touched it (34.8 MB per launch for 21.7 MB of contract, PMC)
+    const int tiles_x = (MW + TL - 1) / TL, tiles_y = (MH + TL - 1) / TL;
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);
+    const int bx0 = (bid % tiles_x) * TL, by0 = ((bid / tiles_x) % tiles_y) * TL, b = bid / (tiles_x * tiles_y);
     const int hw = h * w, V = A * A;
     const float* Gb = G + (size_t)b * V * hw * gld;
     {   // every piece of the staging is requested before the first one is written to LDS (branch-free, from clamped addresses): one
@@ -833,15 +837,55 @@ __global__ __launch_bounds__(256) void k_assemble_t(const float* __restrict__ lr
             if (pidx < NPC) *reinterpret_cast<f32x4*>(gs + slot * GP + part * 4) = in ? vv[i] : f32x4{0, 0, 0, 0};
         }
     }
+    // The bicubic taps of the block: when the views are whole numbers of blocks (h, w multiples of 8 -- every BASELINE shape) the block
+    // lies inside ONE view and its taps are the 12 x 12 LR pixels around it, clamped to that view: staged once per workgroup (they were
+    // 16 cache-line-scattered global loads per output pixel), already clamped, so a tap is one LDS read.  A thread's pixels (rows 256 / TS
+    // apart, same column) share their sub-pixel phase (Y mod S, X mod S): the cubic weights are computed once per thread.  Same values,
+    // same order of additions as bicubic_at: bit-identical.  Other shapes take bicubic_at per pixel.
+    constexpr int LT = TL + 4;
+    __shared__ float lt[LT * LT];
+    const bool one_view = (h % TL == 0) && (w % TL == 0);
+    if (one_view && threadIdx.x < LT * LT) {
+        const int r = threadIdx.x / LT, c = threadIdx.x - r * LT;
+        const int vy0 = (by0 / h) * h, vx0 = (bx0 / w) * w;
+        const int yy = min(max(by0 - 2 + r, vy0), vy0 + h - 1), xx = min(max(bx0 - 2 + c, vx0), vx0 + w - 1);
+        lt[threadIdx.x] = lr[(size_t)b * MH * MW + (size_t)yy * MW + xx];
+    }
     __syncthreads();
     unsigned bad = 0;                                                  // the network's output is the last place an overflow can show
+    float cy[4] = {0, 0, 0, 0}, cx[4] = {0, 0, 0, 0};
+    int ry = 0, rx = 0;                                                // tile row / column of the first tap, relative to the pixel's LR cell
+    if (one_view) {
+        const int Yl0 = threadIdx.x / TS, Xl0 = threadIdx.x - Yl0 * TS;               // (TS * TS is a multiple of 256 or equal to it: every thread has a first pixel)
+        const float sy = ((float)Yl0 + 0.5f) / (float)S - 0.5f, sx = ((float)Xl0 + 0.5f) / (float)S - 0.5f;   // S is a power of two: exact, and so is the
+        const float fy = floorf(sy), fx = floorf(sx);                                                        // fraction, whichever multiple of S is added to Y
+        cubic_coef(sy - fy, cy);
+        cubic_coef(sx - fx, cx);
+        ry = (int)fy - Yl0 / S;                                        // -1 or 0: floor(src) relative to the LR cell of the pixel
+        rx = (int)fx - Xl0 / S;
+    }
     for (int idx = threadIdx.x; idx < TS * TS; idx += 256) {
         const int Yl = idx / TS, Xl = idx - Yl * TS;
         const int Y = by0 * S + Yl, X = bx0 * S + Xl;
         if (Y >= HR_H || X >= HR_W) continue;
-        const int a1 = Y / (h * S), a2 = X / (w * S);
-        const float* view = lr + (size_t)b * MH * MW + (size_t)(a1 * h) * MW + a2 * w;
-        float v = bicubic_at(view, MW, h, w, Y - a1 * h * S, X - a2 * w * S, S);
+        float v;
+        if (one_view) {
+            // LR cell (Yl / S, Xl / S) of the block = tile (2 + Yl / S, 2 + Xl / S); taps floor - 1 .. floor + 2
+            const float* t0 = lt + (2 + Yl / S + ry - 1) * LT + (2 + Xl / S + rx - 1);
+            float acc = 0.0f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float row = 0.0f;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) row += cx[bb] * t0[a * LT + bb];
+                acc += cy[a] * row;
+            }
+            v = acc;
+        } else {
+            const int a1 = Y / (h * S), a2 = X / (w * S);
+            const float* view = lr + (size_t)b * MH * MW + (size_t)(a1 * h) * MW + a2 * w;
+            v = bicubic_at(view, MW, h, w, Y - a1 * h * S, X - a2 * w * S, S);
+        }
         const int ql = Yl / S + 1, qc = Xl / S + 1, i = Yl % S, j = Xl % S;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy) {
