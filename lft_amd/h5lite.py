@@ -34,6 +34,17 @@ class H5Error(Exception):
     pass
 
 
+def _guard(fn, what: str):
+    """A damaged file must end in H5Error, not in an index / value / zlib error from the middle of the parser (or a recursion
+    without end through a B-tree that points at itself)."""
+    try:
+        return fn()
+    except H5Error:
+        raise
+    except (IndexError, ValueError, OverflowError, KeyError, TypeError, RecursionError, MemoryError, zlib.error, UnicodeDecodeError) as e:
+        raise H5Error(f"{what}: damaged or unsupported file ({type(e).__name__}: {e})") from e
+
+
 class _Buf:
     """Little-endian cursor over the file image."""
 
@@ -70,7 +81,7 @@ class Dataset:
         return int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
 
     def read(self) -> np.ndarray:
-        return self._f._read_dataset(self)
+        return _guard(lambda: self._f._read_dataset(self), self.name)
 
     def __array__(self, dtype=None, copy=None):
         a = self.read()
@@ -105,7 +116,9 @@ class Group:
         for i, part in enumerate(parts):
             if not isinstance(node, Group) or part not in node._links:
                 raise KeyError(path)
-            node = self._f._object(node._links[part], "/" + "/".join(parts[:i + 1]))
+            name = "/" + "/".join(parts[:i + 1])
+            addr = node._links[part]
+            node = _guard(lambda: self._f._object(addr, name), name)
         return node
 
 
@@ -123,9 +136,12 @@ class File(Group):
             raise H5Error(f"{path}: empty file")
         self._cache: Dict[int, object] = {}
         try:
-            root = self._superblock()
+            root = _guard(self._superblock, path)
             Group.__init__(self, self, "/", {})
-            self._links = self._object(root, "/")._links
+            rootobj = _guard(lambda: self._object(root, "/"), path)
+            if not isinstance(rootobj, Group):
+                raise H5Error(f"{path}: the root object is not a group")
+            self._links = rootobj._links
         except Exception:
             self.close()
             raise
@@ -199,8 +215,14 @@ class File(Group):
                 b.skip(4)
             size = b.u(1 << (flags & 3))
             blocks = [(b.p, size)]
+            nblocks = 0
             while blocks:
+                nblocks += 1
+                if nblocks > 4096:
+                    raise H5Error("object header continuation chain without end")
                 p, n = blocks.pop(0)
+                if n < 0 or p + n > len(self._mm):
+                    raise H5Error(f"object header at {addr:#x}: a message block of {n} bytes at {p:#x} lies outside the file")
                 c = _Buf(self._mm, p)
                 end = p + n
                 while c.p + 4 <= end:
@@ -227,8 +249,14 @@ class File(Group):
         size = b.u(4)
         b.align(8, addr + self.base)
         blocks = [(b.p, size)]
+        nblocks = 0
         while blocks and len(msgs) < nmsg + 64:
+            nblocks += 1
+            if nblocks > 4096:
+                raise H5Error("object header continuation chain without end")
             p, n = blocks.pop(0)
+            if n < 0 or p + n > len(self._mm):
+                raise H5Error(f"object header at {addr:#x}: a message block of {n} bytes at {p:#x} lies outside the file")
             c = _Buf(self._mm, p)
             while c.p + 8 <= p + n:
                 t, sz, mfl = c.u(2), c.u(2), c.u(1)
@@ -466,6 +494,8 @@ class File(Group):
 
     def _read_dataset(self, ds: Dataset) -> np.ndarray:
         lay, n, es = ds._layout, ds.size, ds.dtype.itemsize
+        if n * es > max(1 << 20, 4096 * len(self._mm)):                # (deflate cannot expand by more than ~1000x)
+            raise H5Error(f"{ds.name}: shape {ds.shape} is not plausible for a file of {len(self._mm)} bytes (damaged header?)")
         if lay["cls"] == 0:
             return np.frombuffer(lay["data"], dtype=ds.dtype, count=n).reshape(ds.shape).copy()
         if lay["cls"] == 1:
