@@ -509,6 +509,14 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
     raw16 qa, qb;
     if constexpr (!TOKLM) q_load_async(qptr, qptr + kQHead, qa, qb);
     Frag<T> of[8];                                                    // attention output of all 8 heads: out_proj's B operand, acc order
+    // Wave priority: the attention phase is bound by vector-instruction issue, the tail behind it by the matrix pipe, and the two waves of
+    // a SIMD are usually in different phases.  Raised priority for the attention phase lets its instructions issue ahead of the other
+    // wave's MFMA chain (which keeps the matrix pipe busy with what it has in flight): k_spa_b -1.8 .. -2.7 % in serial traces on three
+    // boxes (51.2 -> 50.3, 53.0 -> 51.6 us), +0.7 % on the bench within one run (9 720 -> 9 786, four rounds each; gpurun_out/r5c).
+    // Priority 1 does nearly the same (-2.1 %); raising it for the prologue as well loses the gain (53.4 us), for the tail instead
+    // changes nothing, for the LayerNorm of the tail as well nothing.  The same device in k_ang's attention phase (+3 %), k_spa1's
+    // LayerNorm (+2.4 %) and k_up's activation (0) did not pay and is not in those kernels.
+    __builtin_amdgcn_s_setprio(3);
 #pragma unroll                        // of[] needs compile-time indices (a runtime index would put it in scratch)
     for (int hg = 0; hg < 4; ++hg) {
         char* const buf = (hg & 1) ? bufB : bufA;
@@ -652,6 +660,7 @@ __global__ __launch_bounds__(256, 2) void k_spa_b(const T* __restrict__ TOK, con
         load_tile_map<4, T>(TOK + tok0 * 128, rt, lane, t, scr);
     }
     LFT_STAMP(26);
+    __builtin_amdgcn_s_setprio(0);                                    // (see the attention loop)
     ring.start();
     linear_ring_at<0, 4, 8>(ring, of, t);                             // t = tok + O Wo^T
     LFT_STAMP(27);
